@@ -1,0 +1,156 @@
+/*
+ * vited.h - C ABI of libvited_hip.so: the MI355X (gfx950) kernels behind the ViT encoder-decoder
+ * hot path of glmanhtu/vit-ed.
+ *
+ * The reference has no FFI of its own (it is pure Python on PyTorch/timm); its boundary for this
+ * path is the module contract of models/vision_transformer.py:13-420.  Each entry point below
+ * replaces the ATen/cuDNN/SDPA call that the cited reference line dispatches implicitly, so a
+ * maintainer binds them with ctypes from the Attention/Block/CrossBlock
+ * forward methods.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes only; no C++ types, no exceptions, no torch types.
+ *  - every pointer is a DEVICE pointer owned by the caller (inputs, outputs, saved tensors and
+ *    workspace); kernels never allocate, free, or retain pointers past the call.
+ *  - `stream` is a hipStream_t passed as void*; every launch goes to it; no entry synchronises,
+ *    so all of them are hipGraph-capturable.
+ *  - return value: 0 (VITED_OK) or a VITED_ERR_* code; vited_strerror() names it.
+ *  - dtype arguments select the activation type (VITED_F32 or VITED_BF16); parameters, the
+ *    residual stream, statistics, gradients of parameters and all accumulation are fp32.
+ *  - strides (ld*, *_bs, *_ts) are in ELEMENTS of the tensor they describe.
+ */
+#ifndef VITED_H
+#define VITED_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VITED_ABI_VERSION 1
+
+#define VITED_OK 0
+#define VITED_ERR_BAD_ARG 1     /* null pointer, non-positive size, misaligned pointer/stride */
+#define VITED_ERR_UNSUPPORTED 2 /* shape/dtype combination no kernel covers */
+#define VITED_ERR_LAUNCH 3      /* hipGetLastError() after the launch */
+#define VITED_ERR_WORKSPACE 4   /* workspace smaller than vited_*_workspace_bytes() */
+
+#define VITED_F32 0
+#define VITED_BF16 1
+
+/* GEMM epilogues (vited_gemm) */
+#define VITED_EPI_STORE 0          /* out = T(acc + bias)                                          */
+#define VITED_EPI_GELU 1           /* out = T(z), out2 = T(gelu_erf(z)), z = acc + bias            */
+#define VITED_EPI_RESIDUAL 2       /* out_f32[orow] = residual[rrow] + acc + bias (row remap below) */
+#define VITED_EPI_MUL_GELU_GRAD 3  /* out = T(acc * gelu_erf'(aux)), aux = saved pre-activation    */
+#define VITED_EPI_STORE_F32 4      /* out_f32 = acc + bias (logits of the head stay fp32)           */
+
+/* B-operand layouts (vited_gemm) */
+#define VITED_B_NK 0 /* B is [N, K] row-major: out = A . B^T  (nn.Linear weight)                   */
+#define VITED_B_KN 1 /* B is [K, N] row-major: out = A . B                                         */
+
+int vited_abi_version(void);
+const char* vited_strerror(int code);
+
+/* Which implementation the last vited_gemm / vited_attention_* call on this thread dispatched to:
+ * 0 = none yet, 1 = portable fp32-FMA kernel, 2 = bf16 MFMA kernel.  Test/diagnostic use. */
+int vited_last_gemm_path(void);
+int vited_last_attention_path(void);
+
+/* ---- data movement -------------------------------------------------------------------------- */
+
+/* dst[i] = (dst_dtype) src[i].  Used for the bf16 shadow of the fp32 master parameters. */
+int vited_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream);
+
+/* dst[c, r] = (dst_dtype) src[r, c]; src is fp32 [rows, cols].  Transposed bf16 weight shadow used
+ * by the input-gradient GEMMs. */
+int vited_cast_transpose(const float* src, void* dst, int dst_dtype, int64_t rows, int64_t cols, void* stream);
+
+/* Patch extraction for timm PatchEmbed's Conv2d(k = s = p) (used at vision_transformer.py:383,391):
+ * out[(b * G*G + py*G + px), (c*p + i)*p + j] = img[idx(b), c, py*p + i, px*p + j]
+ * img is fp32 with batch stride img_bs (so x[:, 0] / x[:, 1] of the stacked pair tensor need no
+ * copy, vision_transformer.py:408); batch_index (nullable int64[B]) gathers images by index
+ * (hisfrag.py:153,226-227) without materialising the gathered copy. */
+int vited_patchify(const float* img, int64_t img_bs, const int64_t* batch_index, void* out, int out_dtype,
+                   int64_t batch, int chans, int img_size, int patch, void* stream);
+
+/* out[b, r] = (out_dtype) in[b, row_offset + r] for r < rows: drops the cls row of a token-gradient
+ * tensor before the patch-embed weight gradient. in is fp32 [batch, in_rows, dim]. */
+int vited_slice_rows_cast(const float* in, void* out, int out_dtype, int64_t batch, int64_t in_rows,
+                          int64_t row_offset, int64_t rows, int64_t dim, void* stream);
+
+/* x[b, 0, :] = cls[:] + pos[0, :] : the cls row of timm _pos_embed (vision_transformer.py:392). */
+int vited_write_cls_row(float* x, const float* cls, const float* pos, int64_t batch, int64_t rows_per_batch,
+                        int64_t dim, void* stream);
+
+/* out[r] = sum_b in[b, r] (fp32 out; in is `in_dtype` [batch, width]).  Deterministic two-pass;
+ * workspace >= vited_sum_rows_workspace_bytes().  Serves bias gradients (column sums) and the
+ * pos_embed / cls_token gradients (batch sums). */
+int64_t vited_sum_rows_workspace_bytes(int64_t batch, int64_t width);
+int vited_sum_rows(const void* in, int in_dtype, int64_t in_ld, float* out, int64_t batch, int64_t width,
+                   float* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---- LayerNorm (nn.LayerNorm(eps=1e-6), vision_transformer.py:101,114,231,244,245,258,348,400) */
+
+/* y[r, :] = (x[r, :] - mean) * rstd * gamma + beta ; saves mean/rstd (fp32 [rows]). */
+int vited_layernorm_fwd(const float* x, int64_t x_ld, const float* gamma, const float* beta, void* y,
+                        int y_dtype, int64_t y_ld, float* mean, float* rstd, int64_t rows, int64_t dim,
+                        float eps, void* stream);
+
+/* dx_out = (dx_in ? dx_in : 0) + LN'(dy); optional low-precision copy of dx_out (dx_lp, may be
+ * null); dgamma/dbeta are OVERWRITTEN with the column sums.  workspace >= *_workspace_bytes. */
+int64_t vited_layernorm_bwd_workspace_bytes(int64_t rows, int64_t dim);
+int vited_layernorm_bwd(const void* dy, int dy_dtype, int64_t dy_ld, const float* x, int64_t x_ld,
+                        const float* gamma, const float* mean, const float* rstd, const float* dx_in,
+                        int64_t dx_in_ld, float* dx_out, int64_t dx_out_ld, void* dx_lp, int dx_lp_dtype,
+                        int64_t dx_lp_ld, float* dgamma, float* dbeta, int64_t rows, int64_t dim,
+                        float* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---- Linear / GEMM (nn.Linear: qkv :34, proj :38, q :151, kv :152, timm Mlp fc1/fc2, head) ---- */
+
+/* acc[m, n] = sum_k A[m, k] * B(n, k), fp32 accumulation; A is `dtype` [M, K] (row stride lda);
+ * B is `dtype`, laid out per b_layout (row stride ldb); then the epilogue (VITED_EPI_*):
+ *   bias      fp32 [N] or null
+ *   aux       `dtype` [M, N] (row stride ldo)        - MUL_GELU_GRAD only
+ *   residual  fp32                                     - RESIDUAL only
+ *   out/out2  `dtype` [M, N] (row stride ldo); for RESIDUAL and STORE_F32 `out` is fp32
+ * RESIDUAL row remap (patch-embed writes tokens behind a cls row and adds a broadcast pos_embed):
+ *   orow = (m / rows_per_batch) * out_rows_per_batch + m % rows_per_batch + row_offset
+ *   rrow = residual_bcast ? (m % rows_per_batch + row_offset) : orow
+ * with rows_per_batch == 0 meaning the identity map (orow = rrow = m). */
+int vited_gemm(const void* A, int64_t lda, const void* B, int64_t ldb, int b_layout, int dtype, int64_t M,
+               int64_t N, int64_t K, int epilogue, const float* bias, const void* aux,
+               const float* residual, void* out, void* out2, int64_t ldo, int64_t rows_per_batch,
+               int64_t out_rows_per_batch, int64_t row_offset, int residual_bcast, void* stream);
+
+/* dW[n, k] = sum_m dY[m, n] * X[m, k] (fp32 [N, K], OVERWRITTEN) and, if dbias != null,
+ * dbias[n] = sum_m dY[m, n].  dY / X are `dtype`.  workspace >= *_workspace_bytes. */
+int64_t vited_linear_bwd_weight_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int vited_linear_bwd_weight(const void* dY, int64_t lddy, const void* X, int64_t ldx, int dtype, int64_t M,
+                            int64_t N, int64_t K, float* dW, float* dbias, float* workspace,
+                            int64_t workspace_bytes, void* stream);
+
+/* ---- attention core (F.scaled_dot_product_attention, vision_transformer.py:63-66,183-186) ----- */
+
+/* o[b, i, h, :] = softmax_j(scale * q[b,i,h,:] . k[b,j,h,:]) v[b,j,h,:]   (no mask, no dropout)
+ * q/k/v are addressed as ptr + b*bs + token*ts + h*head_dim (+d), so the packed qkv [B,N,3,h,hd]
+ * (:58) and kv [B,Nc,2,h,hd] (:178) projections are consumed in place.  o is [B, Nq, H*hd] with
+ * token stride o_ts; lse (fp32 [B, H, Nq]) = log sum exp of the scaled scores, saved for backward. */
+int vited_attention_fwd(const void* q, int64_t q_bs, int64_t q_ts, const void* k, int64_t k_bs, int64_t k_ts,
+                        const void* v, int64_t v_bs, int64_t v_ts, void* o, int64_t o_bs, int64_t o_ts,
+                        float* lse, int dtype, int64_t batch, int heads, int64_t nq, int64_t nk, int head_dim,
+                        float scale, void* stream);
+
+/* dq/dk/dv in the same strided layouts; delta (fp32 [B, H, Nq]) is scratch for rowsum(dO * O). */
+int vited_attention_bwd(const void* q, int64_t q_bs, int64_t q_ts, const void* k, int64_t k_bs, int64_t k_ts,
+                        const void* v, int64_t v_bs, int64_t v_ts, const void* o, const void* d_o,
+                        int64_t o_bs, int64_t o_ts, const float* lse, float* delta, void* dq, int64_t dq_bs,
+                        int64_t dq_ts, void* dk, int64_t dk_bs, int64_t dk_ts, void* dv, int64_t dv_bs,
+                        int64_t dv_ts, int dtype, int64_t batch, int heads, int64_t nq, int64_t nk,
+                        int head_dim, float scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VITED_H */

@@ -1,0 +1,159 @@
+"""Whole-path parity on the GPU: the HIP ViT-ED (through the C ABI) against
+ (1) the golden fixtures produced by the reference's own classes (tests/golden, see
+     oracle/pin_against_reference.py), and
+ (2) the CPU fp32 oracle on seeded random inputs / reference-style random init.
+
+Tolerances
+  * fp32 kernels ("exact" path): rtol 1e-3 on logits - the tolerance BASELINE.json's north_star
+    states - and rtol 2e-3 on per-parameter gradient norms (measured error is ~1e-5).
+  * bf16 MFMA path: logits within 3e-2 (abs + rel), gradient norms within 5 %.  For scale: PyTorch's
+    own CPU bf16-autocast of the reference deviates by up to 8e-3 abs on logits of magnitude 0.4
+    (SURVEY.md section 7), so rtol 1e-3 is not a bf16 tolerance for anybody.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vited_oracle as vo
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def _fixture(name):
+    return np.load(os.path.join(GOLDEN, f'vited_{name}.npz'))
+
+
+def _shape_of(fx):
+    img, p, c, ncls, d, depth, cdepth, heads = [int(v) for v in fx['shape']]
+    return vo.ViTEDShape(img_size=img, patch_size=p, in_chans=c, num_classes=ncls, embed_dim=d, depth=depth,
+                         c_depth=cdepth, num_heads=heads)
+
+
+def _hip_model(vited, s, gpu, dtype):
+    m = vited.VisionTransformerCustom(img_size=s.img_size, patch_size=s.patch_size, in_chans=s.in_chans,
+                                      num_classes=s.num_classes, embed_dim=s.embed_dim, depth=s.depth, c_depth=s.c_depth,
+                                      num_heads=s.num_heads, mlp_ratio=s.mlp_ratio, qkv_bias=s.qkv_bias)
+    m.compute_dtype = dtype
+    return m.to(gpu)
+
+
+def _targets(batch, s, dev):
+    return (vo.closed_form((batch, s.num_classes), 77, 1.0) > 0.2).float().to(dev)
+
+
+@pytest.mark.parametrize('name', ['T', 'A_1x1', 'A_2x2', 'H_1x1_128', 'A_full', 'H_full'])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_against_reference_fixtures(vited, gpu, name, dtype):
+    fx = _fixture(name)
+    s, batch = _shape_of(fx), int(fx['batch'])
+    model = vo.fill_closed_form_(_hip_model(vited, s, gpu, dtype))
+    x = vo.closed_form_pairs(batch, s).to(gpu)
+    exact = dtype == torch.float32
+    ltol = dict(rtol=1e-3, atol=1e-4) if exact else dict(rtol=3e-2, atol=3e-2)
+    has_bwd = 'loss' in fx
+    with torch.set_grad_enabled(has_bwd):
+        feats = model(x[:, 0], forward_first_part=True)
+        logits = model(x)
+        two_stage = model(feats, x[:, 1])
+    assert logits.dtype == torch.float32 and feats.dtype == torch.float32
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), fx['logits'], **ltol)
+    # structural invariant the reference's only test relies on: two-stage == one-shot
+    assert torch.equal(two_stage, logits)
+    ftol = dict(rtol=1e-3, atol=1e-4) if exact else dict(rtol=5e-2, atol=5e-2)
+    np.testing.assert_allclose(feats[:, :4, :].detach().cpu().numpy(), fx['feats_slice'], **ftol)
+    if not has_bwd:
+        return
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(logits, _targets(batch, s, gpu))
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), float(fx['loss']), rtol=1e-4 if exact else 3e-2)
+    grads = dict(model.named_parameters())
+    names = [str(n) for n in fx['grad_names']]
+    assert names == [n for n, _ in model.named_parameters()]
+    got = np.array([float(grads[n].grad.double().norm()) for n in names])
+    want = fx['grad_norms']
+    gt = dict(rtol=2e-3, atol=1e-6) if exact else dict(rtol=5e-2, atol=2e-3 * float(want.max()))
+    np.testing.assert_allclose(got, want, **gt)
+    st = dict(rtol=2e-3, atol=1e-5 * float(want.max())) if exact else dict(rtol=1e-1, atol=2e-3 * float(want.max()))
+    np.testing.assert_allclose(grads['head.weight'].grad.cpu().numpy(), fx['grad_head_weight'], **st)
+    np.testing.assert_allclose(grads['cls_token'].grad.cpu().numpy(), fx['grad_cls_token'], **st)
+    np.testing.assert_allclose(grads['pos_embed'].grad[0, :3, :16].cpu().numpy(), fx['grad_pos_embed_slice'], **st)
+    np.testing.assert_allclose(grads['blocks.0.attn.qkv.weight'].grad[:8, :8].cpu().numpy(), fx['grad_qkv0_slice'], **st)
+    np.testing.assert_allclose(grads['cross_blocks.0.cross_attn.kv.weight'].grad[:8, :8].cpu().numpy(),
+                               fx['grad_kv0_slice'], **st)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_against_oracle_random_init(vited, gpu, dtype):
+    """Reference-style random init + seeded gaussian pairs, config A at depth 2+2, batch 8."""
+    torch.manual_seed(0)
+    s = vo.ViTEDShape(depth=2, c_depth=2)
+    oracle = vo.OracleViTED(s)
+    model = _hip_model(vited, s, gpu, dtype)
+    model.load_state_dict(oracle.state_dict())
+    x = torch.randn(8, 2, 3, 64, 64).clamp(-1, 1)
+    y = (torch.rand(8, 4) > 0.75).float()
+    lo = oracle(x)
+    torch.nn.functional.binary_cross_entropy_with_logits(lo, y).backward()
+    lh = model(x.to(gpu))
+    torch.nn.functional.binary_cross_entropy_with_logits(lh, y.to(gpu)).backward()
+    exact = dtype == torch.float32
+    torch.testing.assert_close(lh.cpu(), lo.detach(), **(dict(rtol=1e-3, atol=1e-5) if exact else dict(rtol=3e-2, atol=3e-2)))
+    og = dict(oracle.named_parameters())
+    for n, p in model.named_parameters():
+        ref = og[n].grad
+        err = (p.grad.cpu() - ref).norm() / (ref.norm() + 1e-12)
+        assert err < (1e-3 if exact else 6e-2), f'{n}: relative gradient error {err:.3e}'
+
+
+def test_train_equals_eval_and_no_grad_saves_nothing(vited, gpu):
+    s = vo.ViTEDShape(depth=1, c_depth=1)
+    model = vo.fill_closed_form_(_hip_model(vited, s, gpu, torch.bfloat16))
+    x = vo.closed_form_pairs(4, s).to(gpu)
+    with torch.no_grad():
+        a = model.train()(x)
+        b = model.eval()(x)
+    assert torch.equal(a, b) and not a.requires_grad
+
+
+def test_autocast_selects_the_mfma_path(vited, gpu):
+    s = vo.ViTEDShape(depth=1, c_depth=1)
+    model = vo.fill_closed_form_(_hip_model(vited, s, gpu, None))
+    x = vo.closed_form_pairs(2, s).to(gpu)
+    with torch.no_grad():
+        y32 = model(x)
+        assert vited.ops.last_paths()[0] == 1          # outside autocast: fp32 kernels
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            y16 = model(x)
+        assert y16.dtype == torch.float32
+    torch.testing.assert_close(y16, y32, rtol=3e-2, atol=3e-2)
+    assert not torch.equal(y16, y32)
+
+
+def test_hisfrag_two_stage_training_step(vited, gpu):
+    """hisfrag.py:117-159: encoder once per image, gather pairs, decoder on pairs, one backward."""
+    s = vo.ViTEDShape(img_size=128, patch_size=16, num_classes=1, num_heads=6, depth=1, c_depth=1)
+    torch.manual_seed(1)
+    oracle = vo.OracleViTED(s)
+    model = _hip_model(vited, s, gpu, torch.float32)
+    model.load_state_dict(oracle.state_dict())
+    imgs = torch.randn(6, 3, 128, 128).clamp(-1, 1)
+    i0 = torch.tensor([0, 0, 1, 2, 4, 5, 3])
+    i1 = torch.tensor([1, 2, 2, 5, 5, 0, 3])
+    labels = torch.tensor([1., 1, 1, 0, 0, 0, 1]).view(-1, 1)
+
+    def step(m, imgs, i0, i1, labels):
+        feats = m(imgs, forward_first_part=True)
+        out = m(feats[i1], imgs[i0])
+        torch.nn.functional.binary_cross_entropy_with_logits(out, labels).backward()
+        return out
+
+    lo = step(oracle, imgs, i0, i1, labels)
+    lh = step(model, imgs.to(gpu), i0.to(gpu), i1.to(gpu), labels.to(gpu))
+    torch.testing.assert_close(lh.cpu(), lo.detach(), rtol=1e-3, atol=1e-5)
+    og = dict(oracle.named_parameters())
+    for n, p in model.named_parameters():
+        err = (p.grad.cpu() - og[n].grad).norm() / (og[n].grad.norm() + 1e-12)
+        assert err < 1e-3, f'{n}: {err:.3e}'

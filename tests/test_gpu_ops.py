@@ -1,0 +1,242 @@
+"""Per-kernel parity on the GPU: every C-ABI entry point against plain PyTorch fp32 of the same op.
+
+Tolerances: fp32 kernels are compared at rtol/atol ~1e-5..1e-4 (fp32 summation-order noise only);
+bf16 kernels are compared against an fp32 reference computed from the SAME bf16-rounded inputs, so
+the only error left is the final bf16 rounding of the output (rel 2^-8 = 3.9e-3) plus fp32
+accumulation order.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+BF16_OUT = dict(rtol=1e-2, atol=1e-2)
+
+
+def _rand(shape, dev, seed, scale=1.0, dtype=torch.float32):
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dev).to(dtype)
+
+
+def test_cast_and_transpose(vited, gpu):
+    ops = vited.ops
+    for n in (1, 3, 4, 1023, 4096 * 3 + 1):
+        x = _rand((n,), gpu, n)
+        assert torch.equal(ops.cast(x, torch.bfloat16), x.to(torch.bfloat16))
+        assert torch.equal(ops.cast(x.to(torch.bfloat16), torch.float32), x.to(torch.bfloat16).float())
+    for r, c in ((384, 1152), (33, 65), (1, 7), (1536, 384)):
+        w = _rand((r, c), gpu, r * c)
+        assert torch.equal(ops.cast_transpose(w, torch.bfloat16), w.t().contiguous().to(torch.bfloat16))
+        assert torch.equal(ops.cast_transpose(w, torch.float32), w.t().contiguous())
+
+
+@pytest.mark.parametrize('S,p,C', [(64, 8, 3), (64, 32, 3), (128, 16, 3), (32, 8, 1)])
+def test_patchify_matches_unfold(vited, gpu, S, p, C):
+    ops = vited.ops
+    pairs = _rand((5, 2, C, S, S), gpu, S + p)
+    for img in (pairs[:, 0], pairs[:, 1], pairs[:, 0].contiguous()):
+        ref = F.unfold(img.contiguous(), kernel_size=p, stride=p).transpose(1, 2).reshape(-1, C * p * p)
+        assert torch.equal(ops.patchify(img, p, torch.float32), ref)
+        assert torch.equal(ops.patchify(img, p, torch.bfloat16), ref.to(torch.bfloat16))
+    idx = torch.tensor([4, 0, 0, 3, 1, 2, 2], device=gpu)
+    img = pairs[:, 1]
+    ref = F.unfold(img[idx].contiguous(), kernel_size=p, stride=p).transpose(1, 2).reshape(-1, C * p * p)
+    assert torch.equal(ops.patchify(img, p, torch.float32, batch_index=idx), ref)
+
+
+def test_slice_rows_cls_and_sum_rows(vited, gpu):
+    ops = vited.ops
+    x = _rand((7, 65, 384), gpu, 1)
+    assert torch.equal(ops.slice_rows_cast(x, 1, 64, torch.float32), x[:, 1:].reshape(-1, 384))
+    assert torch.equal(ops.slice_rows_cast(x, 1, 64, torch.bfloat16), x[:, 1:].reshape(-1, 384).to(torch.bfloat16))
+    cls, pos = _rand((384,), gpu, 2), _rand((65, 384), gpu, 3)
+    y = x.clone()
+    ops.write_cls_row(y, cls, pos)
+    assert torch.equal(y[:, 0], (cls + pos[0]).expand(7, -1)) and torch.equal(y[:, 1:], x[:, 1:])
+    for b, w in ((1, 5), (17, 384), (1000, 1536), (4096, 384), (33, 65 * 384)):
+        t = _rand((b, w), gpu, b + w)
+        torch.testing.assert_close(ops.sum_rows(t), t.double().sum(0).float(), rtol=1e-5, atol=1e-4 * math.sqrt(b))
+        tb = t.to(torch.bfloat16)
+        torch.testing.assert_close(ops.sum_rows(tb), tb.double().sum(0).float(), rtol=1e-5, atol=1e-4 * math.sqrt(b))
+    # determinism
+    t = _rand((4096, 384), gpu, 9)
+    assert torch.equal(ops.sum_rows(t), ops.sum_rows(t))
+
+
+@pytest.mark.parametrize('rows,dim', [(1, 32), (65, 384), (1000, 384), (130, 768), (7, 48)])
+def test_layernorm_fwd_bwd(vited, gpu, rows, dim):
+    ops = vited.ops
+    x = _rand((rows, dim), gpu, rows, 2.0) + 0.5
+    g, b = _rand((dim,), gpu, 1) * 0.2 + 1, _rand((dim,), gpu, 2) * 0.1
+    dy = _rand((rows, dim), gpu, 3)
+    xr, gr, br = x.clone().requires_grad_(), g.clone().requires_grad_(), b.clone().requires_grad_()
+    yr = F.layer_norm(xr, (dim,), gr, br, 1e-6)
+    yr.backward(dy)
+    y, mean, rstd = ops.layernorm_fwd(x, g, b, 1e-6, torch.float32)
+    torch.testing.assert_close(y, yr.detach(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(mean, x.mean(1), rtol=1e-5, atol=1e-6)
+    y16, _, _ = ops.layernorm_fwd(x, g, b, 1e-6, torch.bfloat16)
+    torch.testing.assert_close(y16.float(), yr.detach(), **BF16_OUT)
+    dx_in = _rand((rows, dim), gpu, 4)
+    dx, lp, dg, db = ops.layernorm_bwd(dy, x, g, mean, rstd, dx_in=dx_in, want_lp=True)
+    torch.testing.assert_close(dx, xr.grad + dx_in, rtol=1e-4, atol=1e-5)
+    assert torch.equal(lp, dx.to(torch.bfloat16))
+    torch.testing.assert_close(dg, gr.grad, rtol=1e-4, atol=1e-4 * math.sqrt(rows))
+    torch.testing.assert_close(db, br.grad, rtol=1e-4, atol=1e-4 * math.sqrt(rows))
+    dx2, lp2, _, _ = ops.layernorm_bwd(dy.to(torch.bfloat16), x, g, mean, rstd)
+    assert lp2 is None
+    xr.grad = None
+    F.layer_norm(xr, (dim,), g, b, 1e-6).backward(dy.to(torch.bfloat16).float())
+    torch.testing.assert_close(dx2, xr.grad, rtol=1e-4, atol=1e-5)
+
+
+def test_layernorm_strided_rows(vited, gpu):
+    """Final norm on the cls rows only: row stride = N2 * D, gradient scattered into a zero tensor."""
+    ops = vited.ops
+    B, N, D = 9, 65, 384
+    x3 = _rand((B, N, D), gpu, 5)
+    g, b = _rand((D,), gpu, 6) + 1, _rand((D,), gpu, 7)
+    y, mean, rstd = ops.layernorm_fwd(x3[:, 0, :], g, b, 1e-6, torch.float32)
+    torch.testing.assert_close(y, F.layer_norm(x3[:, 0, :], (D,), g, b, 1e-6), rtol=1e-5, atol=1e-5)
+    dy = _rand((B, D), gpu, 8)
+    dx = torch.zeros_like(x3)
+    lp = torch.zeros((B, N, D), dtype=torch.bfloat16, device=gpu)
+    ops.layernorm_bwd(dy, x3[:, 0, :], g, mean, rstd, dx_out=dx[:, 0, :], dx_lp=lp[:, 0, :])
+    xr = x3.clone().requires_grad_()
+    F.layer_norm(xr[:, 0, :], (D,), g, b, 1e-6).backward(dy)
+    torch.testing.assert_close(dx, xr.grad, rtol=1e-4, atol=1e-5)
+    assert torch.equal(lp, dx.to(torch.bfloat16))
+
+
+def _gemm_ref(a, w_nk, bias):
+    acc = a.double() @ w_nk.double().t()
+    if bias is not None:
+        acc = acc + bias.double()
+    return acc
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('M,N,K', [(256, 384, 384), (130, 1152, 384), (65, 384, 1536), (200, 128, 192), (33, 4, 384),
+                                   (70, 32, 32), (128, 384, 64)])
+def test_gemm_all_epilogues(vited, gpu, dtype, M, N, K):
+    ops, L = vited.ops, vited._lib
+    a = _rand((M, K), gpu, 1, dtype=dtype)
+    w = _rand((N, K), gpu, 2, 1 / math.sqrt(K), dtype=dtype)
+    bias = _rand((N,), gpu, 3)
+    tol = dict(rtol=2e-4, atol=2e-4) if dtype == torch.float32 else BF16_OUT
+    expect_mfma = dtype == torch.bfloat16 and K % 64 == 0 and N % 16 == 0
+    ref = _gemm_ref(a, w, bias)
+    out = ops.gemm(a, w, bias=bias)
+    assert ops.last_paths()[0] == (2 if expect_mfma else 1)
+    torch.testing.assert_close(out.double(), ref, **tol)
+    torch.testing.assert_close(ops.gemm(a, w).double(), _gemm_ref(a, w, None), **tol)
+    # B given as [K, N]
+    out_kn = ops.gemm(a, w.t().contiguous(), b_layout=L.B_KN, bias=bias)
+    torch.testing.assert_close(out_kn.double(), ref, **tol)
+    # GELU: pre-activation + activation
+    z, u = ops.gemm(a, w, epilogue=L.EPI_GELU, bias=bias)
+    torch.testing.assert_close(z.double(), ref, **tol)
+    torch.testing.assert_close(u.double(), F.gelu(ref), **tol)
+    # fp32 store
+    o32 = ops.gemm(a, w, epilogue=L.EPI_STORE_F32, bias=bias)
+    assert o32.dtype == torch.float32
+    torch.testing.assert_close(o32.double(), ref, rtol=2e-4, atol=2e-4)
+    # residual (fp32 stream)
+    res = _rand((M, N), gpu, 4)
+    y = ops.gemm(a, w, epilogue=L.EPI_RESIDUAL, bias=bias, residual=res)
+    assert y.dtype == torch.float32
+    torch.testing.assert_close(y.double(), ref + res.double(), rtol=2e-4, atol=2e-4)
+    # multiply by gelu'(aux)
+    aux = _rand((M, N), gpu, 5, dtype=dtype)
+    xg = aux.double().requires_grad_()
+    F.gelu(xg).sum().backward()
+    dz = ops.gemm(a, w, epilogue=L.EPI_MUL_GELU_GRAD, aux=aux)
+    torch.testing.assert_close(dz.double(), _gemm_ref(a, w, None) * xg.grad, **tol)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_gemm_patch_embed_row_remap(vited, gpu, dtype):
+    """RESIDUAL epilogue with the cls-row remap and the broadcast pos_embed table."""
+    ops, L = vited.ops, vited._lib
+    B, N1, D, K = 6, 64, 384, 192
+    patches = _rand((B * N1, K), gpu, 1, dtype=dtype)
+    w = _rand((D, K), gpu, 2, 0.1, dtype=dtype)
+    bias, pos = _rand((D,), gpu, 3), _rand((N1 + 1, D), gpu, 4)
+    tok = (_gemm_ref(patches, w, bias)).view(B, N1, D)
+    x = ops.gemm(patches, w, epilogue=L.EPI_RESIDUAL, bias=bias, residual=pos, rows_per_batch=N1,
+                 out_rows_per_batch=N1 + 1, row_offset=1, residual_bcast=True, out_rows=B * (N1 + 1))
+    torch.testing.assert_close(x.view(B, N1 + 1, D)[:, 1:].double(), tok + pos[1:].double(), rtol=2e-4, atol=2e-4)
+    x1 = ops.gemm(patches, w, epilogue=L.EPI_RESIDUAL, bias=bias, residual=pos[1:], rows_per_batch=N1,
+                  out_rows_per_batch=N1, row_offset=0, residual_bcast=True, out_rows=B * N1)
+    torch.testing.assert_close(x1.view(B, N1, D).double(), tok + pos[1:].double(), rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('M,N,K', [(4096, 384, 384), (1000, 1152, 384), (777, 384, 1536), (640, 384, 192), (65, 4, 384),
+                                   (130, 32, 32), (50, 768, 384)])
+def test_linear_bwd_weight(vited, gpu, dtype, M, N, K):
+    ops = vited.ops
+    dy = _rand((M, N), gpu, 1, dtype=dtype)
+    x = _rand((M, K), gpu, 2, dtype=dtype)
+    dw, db = ops.linear_bwd_weight(dy, x)
+    expect_mfma = dtype == torch.bfloat16 and N % 8 == 0 and K % 8 == 0
+    assert ops.last_paths()[0] == (2 if expect_mfma else 1)
+    ref = dy.double().t() @ x.double()
+    torch.testing.assert_close(dw.double(), ref, rtol=1e-4, atol=1e-4 * math.sqrt(M))
+    torch.testing.assert_close(db.double(), dy.double().sum(0), rtol=1e-4, atol=1e-4 * math.sqrt(M))
+    dw2, db2 = ops.linear_bwd_weight(dy, x)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)  # deterministic (slabs, no atomics)
+
+
+def _sdpa_ref(q, k, v, heads, scale):
+    B, Nq, D = q.shape
+    hd = D // heads
+    qh, kh, vh = (t.double().view(B, -1, heads, hd).transpose(1, 2) for t in (q, k, v))
+    s = (qh @ kh.transpose(-1, -2)) * scale
+    p = torch.softmax(s, -1)
+    return (p @ vh).transpose(1, 2).reshape(B, Nq, D), torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('B,H,Nq,Nk,hd', [(3, 12, 64, 64, 32), (3, 12, 65, 65, 32), (2, 12, 65, 64, 32), (2, 6, 257, 256, 64),
+                                          (1, 6, 1025, 1024, 64), (2, 1, 5, 4, 32), (1, 2, 1, 1, 64)])
+def test_attention_fwd_bwd(vited, gpu, dtype, B, H, Nq, Nk, hd):
+    ops = vited.ops
+    D = H * hd
+    scale = hd ** -0.5
+    self_attn = Nq == Nk
+    if self_attn:  # packed qkv projection [B, N, 3, H, hd], consumed in place
+        qkv = _rand((B, Nq, 3 * D), gpu, 1, dtype=dtype)
+        q, k, v = qkv[:, :, :D], qkv[:, :, D:2 * D], qkv[:, :, 2 * D:]
+    else:          # q [B, Nq, D] + packed kv [B, Nk, 2, H, hd]
+        q = _rand((B, Nq, D), gpu, 1, dtype=dtype)
+        kv = _rand((B, Nk, 2 * D), gpu, 2, dtype=dtype)
+        k, v = kv[:, :, :D], kv[:, :, D:]
+    o, lse = ops.attention_fwd(q, k, v, H, scale)
+    qr, kr, vr = (t.double().clone().requires_grad_() for t in (q, k, v))
+    o_ref, lse_ref = _sdpa_ref(qr, kr, vr, H, scale)
+    tol = dict(rtol=1e-4, atol=1e-5) if dtype == torch.float32 else BF16_OUT
+    torch.testing.assert_close(o.double(), o_ref.detach(), **tol)
+    torch.testing.assert_close(lse.double(), lse_ref.detach(), rtol=1e-4, atol=1e-4)
+    do = _rand((B, Nq, D), gpu, 3, dtype=dtype)
+    o_ref.backward(do.double())
+    if self_attn:
+        dqkv = torch.empty_like(qkv)
+        dq, dk, dv = dqkv[:, :, :D], dqkv[:, :, D:2 * D], dqkv[:, :, 2 * D:]
+    else:
+        dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+        dk, dv = dkv[:, :, :D], dkv[:, :, D:]
+    # the kernels consume the SAVED (storage-dtype) output o, like the reference's SDPA backward
+    ops.attention_bwd(q, k, v, o, do, lse, H, scale, dq, dk, dv)
+    btol = dict(rtol=2e-4, atol=2e-5) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(dq.double(), qr.grad, **btol)
+    torch.testing.assert_close(dk.double(), kr.grad, **btol)
+    torch.testing.assert_close(dv.double(), vr.grad, **btol)
+
+
+def test_ops_refuse_cpu_tensors(vited, gpu):
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        vited.ops.cast(torch.zeros(4), torch.bfloat16)

@@ -1,0 +1,230 @@
+// Data-movement kernels of the ViT-ED path: casts, weight-shadow transposes, patch extraction,
+// cls/pos rows and deterministic row sums.  All HBM-bound; loads/stores are coalesced and (where the
+// shape allows) 16 B per lane.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+// cast
+// ------------------------------------------------------------------------------------------------
+template <typename S, typename D>
+__global__ void cast_kernel(const S* __restrict__ src, D* __restrict__ dst, int64_t n) {
+    int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+    for (; i + 3 < n; i += stride) {
+        S a = src[i], b = src[i + 1], c = src[i + 2], d = src[i + 3];
+        dst[i] = from_f32<D>(to_f32(a));
+        dst[i + 1] = from_f32<D>(to_f32(b));
+        dst[i + 2] = from_f32<D>(to_f32(c));
+        dst[i + 3] = from_f32<D>(to_f32(d));
+    }
+    for (; i < n; ++i) dst[i] = from_f32<D>(to_f32(src[i]));  // only the thread that owns the ragged tail gets here
+}
+
+extern "C" int vited_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream) {
+    if (!src || !dst || n < 0) return VITED_ERR_BAD_ARG;
+    if (n == 0) return VITED_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int threads = 256;
+    int64_t blocks = ceil_div64(n, threads * 4);
+    if (blocks > 4096) blocks = 4096;
+    if (src_dtype == VITED_F32 && dst_dtype == VITED_BF16)
+        hipLaunchKernelGGL((cast_kernel<float, bf16>), dim3(blocks), dim3(threads), 0, s, (const float*)src, (bf16*)dst, n);
+    else if (src_dtype == VITED_BF16 && dst_dtype == VITED_F32)
+        hipLaunchKernelGGL((cast_kernel<bf16, float>), dim3(blocks), dim3(threads), 0, s, (const bf16*)src, (float*)dst, n);
+    else if (src_dtype == VITED_F32 && dst_dtype == VITED_F32)
+        hipLaunchKernelGGL((cast_kernel<float, float>), dim3(blocks), dim3(threads), 0, s, (const float*)src, (float*)dst, n);
+    else if (src_dtype == VITED_BF16 && dst_dtype == VITED_BF16)
+        hipLaunchKernelGGL((cast_kernel<bf16, bf16>), dim3(blocks), dim3(threads), 0, s, (const bf16*)src, (bf16*)dst, n);
+    else
+        return VITED_ERR_UNSUPPORTED;
+    return vited_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------
+// cast + transpose through a padded 32x32 LDS tile (both sides coalesced)
+// ------------------------------------------------------------------------------------------------
+template <typename D>
+__global__ void cast_transpose_kernel(const float* __restrict__ src, D* __restrict__ dst, int64_t rows, int64_t cols) {
+    __shared__ float tile[32][33];
+    const int64_t c0 = (int64_t)blockIdx.x * 32, r0 = (int64_t)blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: 32 x 8
+    for (int j = ty; j < 32; j += 8) {
+        int64_t r = r0 + j, c = c0 + tx;
+        tile[j][tx] = (r < rows && c < cols) ? src[r * cols + c] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        int64_t c = c0 + j, r = r0 + tx;
+        if (c < cols && r < rows) dst[c * rows + r] = from_f32<D>(tile[tx][j]);
+    }
+}
+
+extern "C" int vited_cast_transpose(const float* src, void* dst, int dst_dtype, int64_t rows, int64_t cols, void* stream) {
+    if (!src || !dst || rows <= 0 || cols <= 0) return VITED_ERR_BAD_ARG;
+    dim3 grid((unsigned)ceil_div64(cols, 32), (unsigned)ceil_div64(rows, 32));
+    hipStream_t s = (hipStream_t)stream;
+    if (dst_dtype == VITED_BF16)
+        hipLaunchKernelGGL((cast_transpose_kernel<bf16>), grid, dim3(256), 0, s, src, (bf16*)dst, rows, cols);
+    else if (dst_dtype == VITED_F32)
+        hipLaunchKernelGGL((cast_transpose_kernel<float>), grid, dim3(256), 0, s, src, (float*)dst, rows, cols);
+    else
+        return VITED_ERR_UNSUPPORTED;
+    return vited_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------
+// patchify: one workgroup per (image, patch-row py): it reads p full image rows per channel
+// (coalesced along x) and writes the G patch rows of the token matrix.
+// ------------------------------------------------------------------------------------------------
+template <typename D>
+__global__ void patchify_kernel(const float* __restrict__ img, int64_t img_bs, const int64_t* __restrict__ bidx,
+                                D* __restrict__ out, int chans, int S, int p) {
+    const int G = S / p;
+    const int64_t b = blockIdx.y;
+    const int py = blockIdx.x;
+    const int64_t src_b = bidx ? bidx[b] : b;
+    const float* base = img + src_b * img_bs;
+    const int Kp = chans * p * p;
+    const int total = chans * p * S;  // elements in this strip: (c, i, x)
+    D* obase = out + (b * G * G + (int64_t)py * G) * Kp;
+    for (int e = threadIdx.x; e < total; e += blockDim.x) {
+        const int x = e % S;
+        const int ci = e / S;  // c * p + i
+        const int i = ci % p, c = ci / p;
+        const float v = base[((int64_t)c * S + (py * p + i)) * S + x];
+        const int px = x / p, j = x - px * p;
+        obase[(int64_t)px * Kp + (c * p + i) * p + j] = from_f32<D>(v);
+    }
+}
+
+extern "C" int vited_patchify(const float* img, int64_t img_bs, const int64_t* batch_index, void* out, int out_dtype,
+                              int64_t batch, int chans, int img_size, int patch, void* stream) {
+    if (!img || !out || batch <= 0 || chans <= 0 || img_size <= 0 || patch <= 0 || img_size % patch) return VITED_ERR_BAD_ARG;
+    dim3 grid(img_size / patch, (unsigned)batch);
+    hipStream_t s = (hipStream_t)stream;
+    if (out_dtype == VITED_BF16)
+        hipLaunchKernelGGL((patchify_kernel<bf16>), grid, dim3(256), 0, s, img, img_bs, batch_index, (bf16*)out, chans, img_size, patch);
+    else if (out_dtype == VITED_F32)
+        hipLaunchKernelGGL((patchify_kernel<float>), grid, dim3(256), 0, s, img, img_bs, batch_index, (float*)out, chans, img_size, patch);
+    else
+        return VITED_ERR_UNSUPPORTED;
+    return vited_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------
+// slice rows + cast
+// ------------------------------------------------------------------------------------------------
+template <typename D>
+__global__ void slice_rows_cast_kernel(const float* __restrict__ in, D* __restrict__ out, int64_t in_rows,
+                                       int64_t row_offset, int64_t rows, int64_t dim, int64_t total) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t per_b = rows * dim;
+    for (; i < total; i += stride) {
+        const int64_t b = i / per_b, rem = i - b * per_b;
+        out[i] = from_f32<D>(in[(b * in_rows + row_offset) * dim + rem]);
+    }
+}
+
+extern "C" int vited_slice_rows_cast(const float* in, void* out, int out_dtype, int64_t batch, int64_t in_rows,
+                                     int64_t row_offset, int64_t rows, int64_t dim, void* stream) {
+    if (!in || !out || batch <= 0 || rows <= 0 || dim <= 0 || row_offset < 0 || row_offset + rows > in_rows) return VITED_ERR_BAD_ARG;
+    const int64_t total = batch * rows * dim;
+    int64_t blocks = ceil_div64(total, 256);
+    if (blocks > 8192) blocks = 8192;
+    hipStream_t s = (hipStream_t)stream;
+    if (out_dtype == VITED_BF16)
+        hipLaunchKernelGGL((slice_rows_cast_kernel<bf16>), dim3(blocks), dim3(256), 0, s, in, (bf16*)out, in_rows, row_offset, rows, dim, total);
+    else if (out_dtype == VITED_F32)
+        hipLaunchKernelGGL((slice_rows_cast_kernel<float>), dim3(blocks), dim3(256), 0, s, in, (float*)out, in_rows, row_offset, rows, dim, total);
+    else
+        return VITED_ERR_UNSUPPORTED;
+    return vited_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------
+// cls row
+// ------------------------------------------------------------------------------------------------
+__global__ void write_cls_row_kernel(float* __restrict__ x, const float* __restrict__ cls, const float* __restrict__ pos,
+                                     int64_t batch, int64_t rows_per_batch, int64_t dim) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = batch * dim;
+    if (i >= total) return;
+    const int64_t b = i / dim, d = i - b * dim;
+    x[b * rows_per_batch * dim + d] = cls[d] + pos[d];
+}
+
+extern "C" int vited_write_cls_row(float* x, const float* cls, const float* pos, int64_t batch, int64_t rows_per_batch,
+                                   int64_t dim, void* stream) {
+    if (!x || !cls || !pos || batch <= 0 || rows_per_batch <= 0 || dim <= 0) return VITED_ERR_BAD_ARG;
+    const int64_t total = batch * dim;
+    hipLaunchKernelGGL(write_cls_row_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       x, cls, pos, batch, rows_per_batch, dim);
+    return vited_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------
+// deterministic sum over the leading dimension: out[r] = sum_b in[b, r]
+// pass 1: grid (ceil(width/256), S) -> partial[s, r]; pass 2: same kernel over the S partial rows.
+// ------------------------------------------------------------------------------------------------
+template <typename S_>
+__global__ void sum_rows_kernel(const S_* __restrict__ in, int64_t in_ld, float* __restrict__ out, int64_t batch,
+                                int64_t width, int64_t rows_per_split) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= width) return;
+    const int64_t b0 = (int64_t)blockIdx.y * rows_per_split;
+    int64_t b1 = b0 + rows_per_split;
+    if (b1 > batch) b1 = batch;
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+    int64_t b = b0;
+    for (; b + 3 < b1; b += 4) {
+        acc0 += to_f32(in[b * in_ld + r]);
+        acc1 += to_f32(in[(b + 1) * in_ld + r]);
+        acc2 += to_f32(in[(b + 2) * in_ld + r]);
+        acc3 += to_f32(in[(b + 3) * in_ld + r]);
+    }
+    for (; b < b1; ++b) acc0 += to_f32(in[b * in_ld + r]);
+    out[(int64_t)blockIdx.y * width + r] = (acc0 + acc1) + (acc2 + acc3);
+}
+
+static inline int64_t sum_rows_splits(int64_t batch, int64_t width) {
+    // aim for >= ~1024 workgroups, at least 16 rows per split
+    const int64_t col_blocks = ceil_div64(width, 256);
+    int64_t s = ceil_div64(1024, col_blocks);
+    const int64_t max_s = ceil_div64(batch, 16);
+    if (s > max_s) s = max_s;
+    if (s < 1) s = 1;
+    return s;
+}
+
+extern "C" int64_t vited_sum_rows_workspace_bytes(int64_t batch, int64_t width) {
+    return sum_rows_splits(batch, width) * width * (int64_t)sizeof(float);
+}
+
+extern "C" int vited_sum_rows(const void* in, int in_dtype, int64_t in_ld, float* out, int64_t batch, int64_t width,
+                              float* workspace, int64_t workspace_bytes, void* stream) {
+    if (!in || !out || batch <= 0 || width <= 0 || in_ld < width) return VITED_ERR_BAD_ARG;
+    const int64_t S = sum_rows_splits(batch, width);
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned col_blocks = (unsigned)ceil_div64(width, 256);
+    float* pass1_out = out;
+    if (S > 1) {
+        if (!workspace || workspace_bytes < S * width * (int64_t)sizeof(float)) return VITED_ERR_WORKSPACE;
+        pass1_out = workspace;
+    }
+    const int64_t rps = ceil_div64(batch, S);
+    if (in_dtype == VITED_F32)
+        hipLaunchKernelGGL((sum_rows_kernel<float>), dim3(col_blocks, (unsigned)S), dim3(256), 0, s, (const float*)in, in_ld, pass1_out, batch, width, rps);
+    else if (in_dtype == VITED_BF16)
+        hipLaunchKernelGGL((sum_rows_kernel<bf16>), dim3(col_blocks, (unsigned)S), dim3(256), 0, s, (const bf16*)in, in_ld, pass1_out, batch, width, rps);
+    else
+        return VITED_ERR_UNSUPPORTED;
+    if (S > 1)
+        hipLaunchKernelGGL((sum_rows_kernel<float>), dim3(col_blocks, 1), dim3(256), 0, s, (const float*)workspace, width, out, S, width, S);
+    return vited_check_launch();
+}
+
+int sum_rows_f32_single_pass(const float* in, int64_t in_ld, float* out, int64_t batch, int64_t width, hipStream_t s) {
+    hipLaunchKernelGGL((sum_rows_kernel<float>), dim3((unsigned)ceil_div64(width, 256), 1), dim3(256), 0, s, in, in_ld, out, batch, width, batch);
+    return vited_check_launch();
+}

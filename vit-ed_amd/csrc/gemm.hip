@@ -1,0 +1,87 @@
+// C-ABI GEMM entry points: argument validation and dispatch between the bf16 MFMA kernels and the
+// portable fp32-FMA kernels.
+#include "gemm_kernels.h"
+
+static thread_local int g_last_gemm_path = 0;
+extern "C" int vited_last_gemm_path(void) { return g_last_gemm_path; }
+
+extern "C" int vited_gemm(const void* A, int64_t lda, const void* B, int64_t ldb, int b_layout, int dtype, int64_t M,
+                          int64_t N, int64_t K, int epilogue, const float* bias, const void* aux, const float* residual,
+                          void* out, void* out2, int64_t ldo, int64_t rows_per_batch, int64_t out_rows_per_batch,
+                          int64_t row_offset, int residual_bcast, void* stream) {
+    if (!A || !B || !out || M <= 0 || N <= 0 || K <= 0 || lda < K || ldo < N) return VITED_ERR_BAD_ARG;
+    if (b_layout != VITED_B_NK && b_layout != VITED_B_KN) return VITED_ERR_BAD_ARG;
+    if (ldb < (b_layout == VITED_B_NK ? K : N)) return VITED_ERR_BAD_ARG;
+    if (epilogue == VITED_EPI_GELU && !out2) return VITED_ERR_BAD_ARG;
+    if (epilogue == VITED_EPI_RESIDUAL && !residual) return VITED_ERR_BAD_ARG;
+    if (epilogue == VITED_EPI_MUL_GELU_GRAD && !aux) return VITED_ERR_BAD_ARG;
+    if (rows_per_batch < 0 || (rows_per_batch > 0 && (out_rows_per_batch < rows_per_batch + row_offset || row_offset < 0)))
+        return VITED_ERR_BAD_ARG;
+    EpiParams ep;
+    ep.bias = bias;
+    ep.aux = aux;
+    ep.residual = residual;
+    ep.out = out;
+    ep.out2 = out2;
+    ep.ldo = ldo;
+    ep.rows_per_batch = epilogue == VITED_EPI_RESIDUAL ? rows_per_batch : 0;
+    ep.out_rows_per_batch = out_rows_per_batch;
+    ep.row_offset = row_offset;
+    ep.residual_bcast = residual_bcast;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == VITED_BF16 && b_layout == VITED_B_NK && gemm_nt_mfma_supported(A, lda, B, ldb, M, N, K, epilogue, ep)) {
+        g_last_gemm_path = 2;
+        return gemm_nt_mfma(A, lda, B, ldb, M, N, K, epilogue, ep, s);
+    }
+    g_last_gemm_path = 1;
+    return gemm_portable(A, lda, B, ldb, b_layout, dtype, M, N, K, epilogue, ep, s);
+}
+
+static inline int64_t tn_portable_splits(int64_t M, int64_t N, int64_t K) {
+    const int64_t tiles = ceil_div64(N, 64) * ceil_div64(K, 64);
+    int64_t s = ceil_div64(1024, tiles);
+    const int64_t max_s = ceil_div64(M, 256);
+    if (s > max_s) s = max_s;
+    if (s < 1) s = 1;
+    const int64_t rps = ceil_div64(ceil_div64(M, s), 16) * 16;
+    return ceil_div64(M, rps);
+}
+
+static inline int64_t max64(int64_t a, int64_t b) { return a > b ? a : b; }
+
+extern "C" int64_t vited_linear_bwd_weight_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+    const int64_t s = max64(tn_portable_splits(M, N, K), gemm_tn_mfma_splits(M, N, K));
+    // slabs for dW + the row-sum workspace for dbias (placed after the slabs)
+    return (s * N * K) * (int64_t)sizeof(float) + vited_sum_rows_workspace_bytes(M, N) + 256;
+}
+
+extern "C" int vited_linear_bwd_weight(const void* dY, int64_t lddy, const void* X, int64_t ldx, int dtype, int64_t M,
+                                       int64_t N, int64_t K, float* dW, float* dbias, float* workspace,
+                                       int64_t workspace_bytes, void* stream) {
+    if (!dY || !X || !dW || M <= 0 || N <= 0 || K <= 0 || lddy < N || ldx < K) return VITED_ERR_BAD_ARG;
+    if (dtype != VITED_F32 && dtype != VITED_BF16) return VITED_ERR_UNSUPPORTED;
+    if (!workspace || workspace_bytes < vited_linear_bwd_weight_workspace_bytes(M, N, K)) return VITED_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const bool mfma = dtype == VITED_BF16 && gemm_tn_mfma_supported(dY, lddy, X, ldx, M, N, K);
+    const int64_t splits = mfma ? gemm_tn_mfma_splits(M, N, K) : tn_portable_splits(M, N, K);
+    float* slab = splits > 1 ? workspace : dW;
+    int rc;
+    if (mfma) {
+        g_last_gemm_path = 2;
+        rc = gemm_tn_mfma(dY, lddy, X, ldx, M, N, K, splits, slab, s);
+    } else {
+        g_last_gemm_path = 1;
+        rc = gemm_tn_portable(dY, lddy, X, ldx, dtype, M, N, K, splits, slab, s);
+    }
+    if (rc != VITED_OK) return rc;
+    if (splits > 1) {  // dW = sum of the slabs (single pass: few slabs, N*K wide)
+        rc = sum_rows_f32_single_pass(workspace, N * K, dW, splits, N * K, s);
+        if (rc != VITED_OK) return rc;
+    }
+    if (dbias) {
+        float* ws2 = workspace + splits * N * K;
+        const int64_t ws2_bytes = workspace_bytes - splits * N * K * (int64_t)sizeof(float);
+        rc = vited_sum_rows(dY, dtype, lddy, dbias, M, N, ws2, ws2_bytes, stream);
+    }
+    return rc;
+}

@@ -1,0 +1,353 @@
+// bf16 MFMA GEMM kernels for gfx950 (CDNA4), the contraction engine of the ViT-ED path.
+//
+//  gemm_nt_mfma_kernel : out = epilogue(A[M,K] . B[N,K]^T)        (Linear fwd, and dX via W^T shadow)
+//  gemm_tn_mfma_kernel : dW[N,K] = sum_m dY[m,N]^T X[m,K], split over M into fp32 slabs
+//
+// Both: 256 threads = 4 waves (2 x 2), 128 x 128 output tile, each wave 64 x 64 = 4 x 4
+// v_mfma_f32_16x16x32_bf16 accumulators; operands staged global -> LDS with 16-byte
+// global_load_lds (LDS-DMA, no VGPR round trip), two LDS stages, one barrier per K-step, the next
+// stage's DMA in flight under the current stage's MFMAs.  LDS images are XOR-swizzled on the
+// SOURCE address (the DMA destination is lane-linear) with the matching XOR on the read, so the
+// ds_read_b128 / ds_read_b64_tr_b16 fragment reads are bank-conflict free.
+// The NT epilogue is staged through LDS so every global access is a 16-byte, row-contiguous one.
+#include "gemm_kernels.h"
+
+#define BM 128
+#define BN 128
+#define BK 64
+#define A_BYTES (BM * BK * 2)
+#define STAGE_BYTES (A_BYTES + BN * BK * 2)
+#define SCRATCH_LD 68  // floats per row of the per-wave epilogue scratch (16 rows)
+#define SCRATCH_BYTES (16 * SCRATCH_LD * 4)
+
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+// bijective XCD-aware remap: blocks that share an XCD (bid % 8) get a contiguous run of tiles
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+// ---- NT: [rows][64 bf16] tiles, 128-byte rows, chunk c of row r lives at c ^ ((r >> 1) & 7) ------
+__device__ __forceinline__ int nt_off(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
+
+__device__ __forceinline__ void nt_stage_load(const bf16* __restrict__ A, int64_t lda, const bf16* __restrict__ B,
+                                              int64_t ldb, int64_t m0, int64_t n0, int64_t M, int64_t N, int64_t k0,
+                                              char* stage, int wave, int lane) {
+    const int rsub = lane >> 3, cp = lane & 7;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = wave * 32 + i * 8 + rsub;
+        const int c = cp ^ ((r >> 1) & 7);
+        int64_t gm = m0 + r;
+        gm = gm < M ? gm : M - 1;
+        int64_t gn = n0 + r;
+        gn = gn < N ? gn : N - 1;
+        glds16(A + gm * lda + k0 + c * 8, stage + (wave * 32 + i * 8) * 128);
+        glds16(B + gn * ldb + k0 + c * 8, stage + A_BYTES + (wave * 32 + i * 8) * 128);
+    }
+}
+
+template <int EPI>
+__device__ __forceinline__ void epilogue_store16(const EpiParams& p, int64_t m, int64_t n, float* v) {
+    if (p.bias) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 b = *(const f32x4*)(p.bias + n + q * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[q * 4 + e] += b[e];
+        }
+    }
+    if constexpr (EPI == VITED_EPI_STORE_F32) {
+        float* o = (float*)p.out + m * p.ldo + n;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *(f32x4*)(o + q * 4) = f32x4{v[q * 4], v[q * 4 + 1], v[q * 4 + 2], v[q * 4 + 3]};
+    } else if constexpr (EPI == VITED_EPI_RESIDUAL) {
+        int64_t orow = m, rrow = m;
+        if (p.rows_per_batch > 0) {
+            const int64_t b = m / p.rows_per_batch, r = m - b * p.rows_per_batch + p.row_offset;
+            orow = b * p.out_rows_per_batch + r;
+            rrow = p.residual_bcast ? r : orow;
+        }
+        const float* res = p.residual + rrow * p.ldo + n;
+        float* o = (float*)p.out + orow * p.ldo + n;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 r4 = *(const f32x4*)(res + q * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r4[e] += v[q * 4 + e];
+            *(f32x4*)(o + q * 4) = r4;
+        }
+    } else {
+        bf16* o = (bf16*)p.out + m * p.ldo + n;
+        if constexpr (EPI == VITED_EPI_MUL_GELU_GRAD) {
+            const bf16* z = (const bf16*)p.aux + m * p.ldo + n;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const bf16x8 zz = *(const bf16x8*)(z + h * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[h * 8 + e] *= gelu_grad_f((float)zz[e]);
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            bf16x8 pk;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pk[e] = (bf16)v[h * 8 + e];
+            *(bf16x8*)(o + h * 8) = pk;
+        }
+        if constexpr (EPI == VITED_EPI_GELU) {
+            bf16* o2 = (bf16*)p.out2 + m * p.ldo + n;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                bf16x8 pk;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pk[e] = (bf16)gelu_f(v[h * 8 + e]);
+                *(bf16x8*)(o2 + h * 8) = pk;
+            }
+        }
+    }
+}
+
+template <int EPI>
+__global__ void __launch_bounds__(256)
+gemm_nt_mfma_kernel(const bf16* __restrict__ A, int64_t lda, const bf16* __restrict__ B, int64_t ldb, int64_t M, int64_t N,
+                    int64_t K, int tiles_n, int ntiles, EpiParams ep) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int tile = xcd_remap(blockIdx.x, ntiles);
+    const int64_t m0 = (int64_t)(tile / tiles_n) * BM, n0 = (int64_t)(tile % tiles_n) * BN;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (int)(K / BK);
+    nt_stage_load(A, lda, B, ldb, m0, n0, M, N, 0, smem, wave, lane);
+    const int fr = lane & 15, fq = lane >> 4;
+    for (int t = 0; t < nk; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // stage t landed for every wave; everyone is done reading stage t-1
+        if (t + 1 < nk)
+            nt_stage_load(A, lda, B, ldb, m0, n0, M, N, (int64_t)(t + 1) * BK, smem + ((t + 1) & 1) * STAGE_BYTES, wave, lane);
+        const char* sa = smem + (t & 1) * STAGE_BYTES;
+        const char* sb = sa + A_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 af[4], bf_[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8*)(sa + nt_off(wr * 64 + i * 16 + fr, kk * 4 + fq));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bf_[j] = *(const bf16x8*)(sb + nt_off(wc * 64 + j * 16 + fr, kk * 4 + fq));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf_[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    // ---- epilogue: accumulators -> per-wave LDS scratch -> 16 contiguous columns per lane ----------
+    __syncthreads();
+    float* sc = (float*)(smem + wave * SCRATCH_BYTES);
+    const int erow = lane >> 2, ecol = (lane & 3) * 16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sc[(fq * 4 + e) * SCRATCH_LD + j * 16 + fr] = acc[i][j][e];
+        __syncthreads();
+        float v[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 t4 = *(const f32x4*)(sc + erow * SCRATCH_LD + ecol + q * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[q * 4 + e] = t4[e];
+        }
+        const int64_t m = m0 + wr * 64 + i * 16 + erow, n = n0 + wc * 64 + ecol;
+        if (m < M && n < N) epilogue_store16<EPI>(ep, m, n, v);
+        __syncthreads();
+    }
+}
+
+bool gemm_nt_mfma_supported(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K,
+                            int epilogue, const EpiParams& ep) {
+    auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+    if (K % BK || N % 16 || lda % 8 || ldb % 8 || ep.ldo % 8) return false;
+    if (!al16(A) || !al16(B) || !al16(ep.out)) return false;
+    if (ep.bias && !al16(ep.bias)) return false;
+    if (epilogue == VITED_EPI_GELU && !al16(ep.out2)) return false;
+    if (epilogue == VITED_EPI_MUL_GELU_GRAD && !al16(ep.aux)) return false;
+    if (epilogue == VITED_EPI_RESIDUAL && !al16(ep.residual)) return false;
+    if (ceil_div64(M, BM) * ceil_div64(N, BN) > (1 << 30)) return false;
+    return true;
+}
+
+int gemm_nt_mfma(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K, int epilogue,
+                 const EpiParams& ep, hipStream_t s) {
+    const int tiles_n = (int)ceil_div64(N, BN);
+    const int ntiles = (int)(ceil_div64(M, BM) * tiles_n);
+    const size_t lds = 2 * STAGE_BYTES;
+    const bf16* a = (const bf16*)A;
+    const bf16* b = (const bf16*)B;
+#define LAUNCH_NT(E) hipLaunchKernelGGL((gemm_nt_mfma_kernel<E>), dim3(ntiles), dim3(256), lds, s, a, lda, b, ldb, M, N, K, tiles_n, ntiles, ep)
+    switch (epilogue) {
+        case VITED_EPI_STORE: LAUNCH_NT(VITED_EPI_STORE); break;
+        case VITED_EPI_GELU: LAUNCH_NT(VITED_EPI_GELU); break;
+        case VITED_EPI_RESIDUAL: LAUNCH_NT(VITED_EPI_RESIDUAL); break;
+        case VITED_EPI_MUL_GELU_GRAD: LAUNCH_NT(VITED_EPI_MUL_GELU_GRAD); break;
+        case VITED_EPI_STORE_F32: LAUNCH_NT(VITED_EPI_STORE_F32); break;
+        default: return VITED_ERR_BAD_ARG;
+    }
+#undef LAUNCH_NT
+    return vited_check_launch();
+}
+
+// ================================================================================================
+// TN (weight gradient): stage = dY tile [64 m][128 n] + X tile [64 m][128 k], 256-byte rows.
+// Image (b) of the guide's dual-use layouts: chunk ch of row r lives at ch ^ (((r&3)<<2)|((r>>2)&3));
+// both MFMA operands are read column-wise with ds_read_b64_tr_b16.
+// ================================================================================================
+#define TM 64
+#define T_TILE_BYTES (TM * 128 * 2)
+#define T_STAGE_BYTES (2 * T_TILE_BYTES)
+
+__device__ __forceinline__ int tn_f(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
+
+__device__ __forceinline__ bf16x4 tr_read(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p);
+}
+
+__device__ __forceinline__ void tn_stage_load(const bf16* __restrict__ dY, int64_t lddy, const bf16* __restrict__ X,
+                                              int64_t ldx, int64_t mrow0, int64_t mlast, int64_t n0, int64_t N,
+                                              int64_t kc0, int64_t K, char* stage, int wave, int lane) {
+    const int rsub = lane >> 4, cp = lane & 15;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = wave * 16 + i * 4 + rsub;
+        const int ch = cp ^ tn_f(r);
+        int64_t gm = mrow0 + r;
+        gm = gm <= mlast ? gm : mlast;  // clamped rows are zeroed in LDS after landing
+        int64_t cn = n0 + ch * 8;
+        cn = cn <= N - 8 ? cn : N - 8;
+        int64_t ck = kc0 + ch * 8;
+        ck = ck <= K - 8 ? ck : K - 8;
+        glds16(dY + gm * lddy + cn, stage + (wave * 16 + i * 4) * 256);
+        glds16(X + gm * ldx + ck, stage + T_TILE_BYTES + (wave * 16 + i * 4) * 256);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+gemm_tn_mfma_kernel(const bf16* __restrict__ dY, int64_t lddy, const bf16* __restrict__ X, int64_t ldx, int64_t M, int64_t N,
+                    int64_t K, int64_t rows_per_split, int tiles_k, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int64_t n0 = (int64_t)(blockIdx.x / tiles_k) * 128, kc0 = (int64_t)(blockIdx.x % tiles_k) * 128;
+    const int64_t mb = (int64_t)blockIdx.y * rows_per_split;
+    int64_t me = mb + rows_per_split;
+    me = me < M ? me : M;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nsteps = me > mb ? (int)((me - mb + TM - 1) / TM) : 0;
+    if (nsteps > 0) tn_stage_load(dY, lddy, X, ldx, mb, me - 1, n0, N, kc0, K, smem, wave, lane);
+    const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    for (int t = 0; t < nsteps; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        char* st = smem + (t & 1) * T_STAGE_BYTES;
+        const int64_t mrow0 = mb + (int64_t)t * TM;
+        if (mrow0 + TM > me) {  // ragged last stage: zero the rows this lane's DMA clamped
+            const int rsub = lane >> 4, cp = lane & 15;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = wave * 16 + i * 4 + rsub;
+                if (mrow0 + r >= me) {
+                    *(f32x4*)(st + r * 256 + cp * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+                    *(f32x4*)(st + T_TILE_BYTES + r * 256 + cp * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        }
+        __syncthreads();
+        if (t + 1 < nsteps)
+            tn_stage_load(dY, lddy, X, ldx, mrow0 + TM, me - 1, n0, N, kc0, K, smem + ((t + 1) & 1) * T_STAGE_BYTES, wave, lane);
+        const char* sy = st;
+        const char* sx = st + T_TILE_BYTES;
+#pragma unroll
+        for (int ms = 0; ms < 2; ++ms) {
+            bf16x8 af[4], bf_[4];
+            const int r_lo = ms * 32 + 8 * g + q, r_hi = r_lo + 4;
+            const int f_lo = tn_f(r_lo), f_hi = tn_f(r_hi);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ch = ((wr * 64 + i * 16) >> 3) + (p >> 1);
+                const bf16x4 lo = tr_read(sy + r_lo * 256 + ((ch ^ f_lo) << 4) + 8 * (p & 1));
+                const bf16x4 hi = tr_read(sy + r_hi * 256 + ((ch ^ f_hi) << 4) + 8 * (p & 1));
+                af[i] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ch = ((wc * 64 + j * 16) >> 3) + (p >> 1);
+                const bf16x4 lo = tr_read(sx + r_lo * 256 + ((ch ^ f_lo) << 4) + 8 * (p & 1));
+                const bf16x4 hi = tr_read(sx + r_hi * 256 + ((ch ^ f_hi) << 4) + 8 * (p & 1));
+                bf_[j] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf_[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    float* o = out + (int64_t)blockIdx.y * N * K;
+    const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t k = kc0 + wc * 64 + j * 16 + fr;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int64_t n = n0 + wr * 64 + i * 16 + fq * 4 + e;
+                if (n < N && k < K) o[n * K + k] = acc[i][j][e];
+            }
+        }
+    }
+}
+
+bool gemm_tn_mfma_supported(const void* dY, int64_t lddy, const void* X, int64_t ldx, int64_t M, int64_t N, int64_t K) {
+    auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+    return N % 8 == 0 && K % 8 == 0 && N >= 8 && K >= 8 && lddy % 8 == 0 && ldx % 8 == 0 && al16(dY) && al16(X) && M >= 1;
+}
+
+int64_t gemm_tn_mfma_splits(int64_t M, int64_t N, int64_t K) {
+    const int64_t tiles = ceil_div64(N, 128) * ceil_div64(K, 128);
+    int64_t s = ceil_div64(512, tiles);
+    const int64_t max_s = ceil_div64(M, 512);
+    if (s > max_s) s = max_s;
+    if (s < 1) s = 1;
+    const int64_t rps = ceil_div64(ceil_div64(M, s), TM) * TM;
+    return ceil_div64(M, rps);
+}
+
+int gemm_tn_mfma(const void* dY, int64_t lddy, const void* X, int64_t ldx, int64_t M, int64_t N, int64_t K, int64_t splits,
+                 float* out, hipStream_t s) {
+    const int tiles_k = (int)ceil_div64(K, 128);
+    const int tiles = (int)ceil_div64(N, 128) * tiles_k;
+    const int64_t rps = ceil_div64(ceil_div64(M, splits), TM) * TM;
+    hipLaunchKernelGGL(gemm_tn_mfma_kernel, dim3(tiles, (unsigned)splits), dim3(256), 2 * T_STAGE_BYTES, s, (const bf16*)dY, lddy,
+                       (const bf16*)X, ldx, M, N, K, rps, tiles_k, out);
+    return vited_check_launch();
+}

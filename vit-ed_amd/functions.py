@@ -1,0 +1,351 @@
+"""Encoder / decoder autograd Functions of the ViT-ED hot path, composed from the HIP ops.
+
+Two coarse Functions instead of ~230 per-op autograd nodes: the whole encoder
+(models/vision_transformer.py:382-388 ``forward_first_part``) and the whole decoder + head
+(:390-405 ``prepare_x2`` / ``cross_part`` / ``forward_second_part`` and timm ``forward_head``).
+Inside each, forward and backward are explicit sequences of kernel launches with hand-managed
+saved activations, which is what lets the residual adds, the low-precision copies of the residual
+gradient and the accumulation of d(context) over the c_depth decoder blocks live in kernel
+epilogues instead of separate elementwise passes.
+
+Data types: the residual stream, LayerNorm statistics, parameters and parameter gradients are
+fp32; activations that feed contractions are ``rt.act_dtype`` (bf16 on the MFMA path, fp32 on the
+exact path).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from ._lib import (B_KN, B_NK, EPI_GELU, EPI_MUL_GELU_GRAD, EPI_RESIDUAL, EPI_STORE, EPI_STORE_F32)
+
+LN_EPS = 1e-6  # partial(nn.LayerNorm, eps=1e-6), vision_transformer.py:348
+
+ENC_BLOCK_KEYS = ('norm1.weight', 'norm1.bias', 'attn.qkv.weight', 'attn.qkv.bias', 'attn.proj.weight',
+                  'attn.proj.bias', 'norm2.weight', 'norm2.bias', 'mlp.fc1.weight', 'mlp.fc1.bias',
+                  'mlp.fc2.weight', 'mlp.fc2.bias')
+DEC_BLOCK_KEYS = ('norm1.weight', 'norm1.bias', 'attn.qkv.weight', 'attn.qkv.bias', 'attn.proj.weight',
+                  'attn.proj.bias', 'norm_cross.weight', 'norm_cross.bias', 'norm_context.weight',
+                  'norm_context.bias', 'cross_attn.q.weight', 'cross_attn.q.bias', 'cross_attn.kv.weight',
+                  'cross_attn.kv.bias', 'cross_attn.proj.weight', 'cross_attn.proj.bias', 'norm2.weight',
+                  'norm2.bias', 'mlp.fc1.weight', 'mlp.fc1.bias', 'mlp.fc2.weight', 'mlp.fc2.bias')
+ENC_SHARED_KEYS = ('patch_embed.proj.weight', 'patch_embed.proj.bias', 'pos_embed')
+DEC_SHARED_KEYS = ('patch_embed.proj.weight', 'patch_embed.proj.bias', 'pos_embed', 'cls_token', 'norm.weight',
+                   'norm.bias', 'head.weight', 'head.bias')
+
+
+class Runtime:
+    """Per-model launch context: static shape, activation dtype and the low-precision weight shadows."""
+
+    def __init__(self, *, img_size, patch_size, in_chans, num_classes, embed_dim, depth, c_depth, num_heads,
+                 act_dtype=torch.bfloat16):
+        self.img_size, self.patch_size, self.in_chans = img_size, patch_size, in_chans
+        self.num_classes, self.dim, self.depth, self.c_depth, self.heads = num_classes, embed_dim, depth, c_depth, num_heads
+        self.n1 = (img_size // patch_size) ** 2
+        self.n2 = self.n1 + 1
+        self.head_dim = embed_dim // num_heads
+        self.scale = self.head_dim ** -0.5
+        self.act_dtype = act_dtype
+        self._shadow = {}
+
+    @property
+    def exact(self):
+        return self.act_dtype == torch.float32
+
+    def weight(self, w: torch.Tensor) -> torch.Tensor:
+        """[N, K] operand of the forward GEMM in the activation dtype (cached per parameter version)."""
+        w2 = w.detach().reshape(w.shape[0], -1)
+        if self.exact:
+            return w2
+        return self._cached(w, 'n', lambda: ops.cast(w2, self.act_dtype))
+
+    def weight_t(self, w: torch.Tensor):
+        """Operand + layout of the input-gradient GEMM dX = dY . W: the transposed bf16 shadow (NT
+        MFMA kernel) or, on the exact path, W itself read as [K, N]."""
+        w2 = w.detach().reshape(w.shape[0], -1)
+        if self.exact:
+            return w2, B_KN
+        return self._cached(w, 't', lambda: ops.cast_transpose(w2.contiguous(), self.act_dtype)), B_NK
+
+    def _cached(self, w, tag, make):
+        key = (id(w), tag)
+        ent = self._shadow.get(key)
+        if ent is None or ent[0] != w._version or ent[1] != w.data_ptr():
+            if torch.cuda.is_current_stream_capturing() and ent is not None:
+                # refresh IN PLACE so a captured graph keeps reading the same buffer
+                ent[2].copy_(make())
+                ent = (w._version, w.data_ptr(), ent[2])
+            else:
+                ent = (w._version, w.data_ptr(), make())
+            self._shadow[key] = ent
+        return ent[2]
+
+    def refresh_shadows(self, params):
+        """Recast every cached shadow in place (call after an optimizer step when replaying a graph)."""
+        by_id = {id(p): p for p in params}
+        for (pid, tag), ent in list(self._shadow.items()):
+            p = by_id.get(pid)
+            if p is None:
+                continue
+            w2 = p.detach().reshape(p.shape[0], -1)
+            fresh = ops.cast(w2, self.act_dtype) if tag == 'n' else ops.cast_transpose(w2.contiguous(), self.act_dtype)
+            ent[2].copy_(fresh)
+            self._shadow[(pid, tag)] = (p._version, p.data_ptr(), ent[2])
+
+
+def _lp(rt: Runtime, t_f32: torch.Tensor) -> torch.Tensor:
+    return t_f32 if rt.exact else ops.cast(t_f32, rt.act_dtype)
+
+
+# ---------------------------------------------------------------------------------------------
+# shared pieces
+# ---------------------------------------------------------------------------------------------
+def _linear_bwd(rt, dy, x_saved, w, want_dx=True, aux=None):
+    """(dx | None, dW, db) of y = x W^T + b given dy (activation dtype)."""
+    dx = None
+    if want_dx:
+        wt, layout = rt.weight_t(w)
+        if aux is not None:
+            dx = ops.gemm(dy, wt, b_layout=layout, epilogue=EPI_MUL_GELU_GRAD, aux=aux)
+        else:
+            dx = ops.gemm(dy, wt, b_layout=layout)
+    dw, db = ops.linear_bwd_weight(dy, x_saved)
+    return dx, dw.view_as(w), db
+
+
+def _self_attn_fwd(rt, h, wqkv, bqkv, batch, n):
+    d = rt.dim
+    qkv = ops.gemm(h, rt.weight(wqkv), bias=bqkv)                   # [M, 3D], columns [3][h][hd] (:58)
+    qkv3 = qkv.view(batch, n, 3 * d)
+    o, lse = ops.attention_fwd(qkv3[:, :, 0:d], qkv3[:, :, d:2 * d], qkv3[:, :, 2 * d:3 * d], rt.heads, rt.scale)
+    return qkv, o.view(batch * n, d), lse
+
+
+def _self_attn_bwd(rt, do, qkv, o, lse, batch, n):
+    d = rt.dim
+    qkv3 = qkv.view(batch, n, 3 * d)
+    dqkv = torch.empty_like(qkv)
+    dqkv3 = dqkv.view(batch, n, 3 * d)
+    ops.attention_bwd(qkv3[:, :, 0:d], qkv3[:, :, d:2 * d], qkv3[:, :, 2 * d:3 * d], o.view(batch, n, d),
+                      do.view(batch, n, d), lse, rt.heads, rt.scale, dqkv3[:, :, 0:d], dqkv3[:, :, d:2 * d],
+                      dqkv3[:, :, 2 * d:3 * d])
+    return dqkv
+
+
+def _mlp_fwd(rt, x, g, b, w1, b1, w2, b2):
+    h, mean, rstd = ops.layernorm_fwd(x, g, b, LN_EPS, rt.act_dtype)
+    z, u = ops.gemm(h, rt.weight(w1), epilogue=EPI_GELU, bias=b1)
+    y = ops.gemm(u, rt.weight(w2), epilogue=EPI_RESIDUAL, bias=b2, residual=x)
+    return y, (mean, rstd, h, z, u)
+
+
+def _mlp_bwd(rt, dy, dy_lp, x, g, w1, w2, saved):
+    mean, rstd, h, z, u = saved
+    dz, dw2, db2 = _linear_bwd(rt, dy_lp, u, w2, aux=z)
+    dh, dw1, db1 = _linear_bwd(rt, dz, h, w1)
+    dx, dx_lp, dg, db = ops.layernorm_bwd(dh, x, g, mean, rstd, dx_in=dy, want_lp=not rt.exact)
+    return dx, (dx if rt.exact else dx_lp), (dg, db, dw1, db1, dw2, db2)
+
+
+def _attn_branch_fwd(rt, x, g, b, wqkv, bqkv, wproj, bproj, batch, n):
+    h, mean, rstd = ops.layernorm_fwd(x, g, b, LN_EPS, rt.act_dtype)
+    qkv, o, lse = _self_attn_fwd(rt, h, wqkv, bqkv, batch, n)
+    y = ops.gemm(o, rt.weight(wproj), epilogue=EPI_RESIDUAL, bias=bproj, residual=x)
+    return y, (mean, rstd, h, qkv, o, lse)
+
+
+def _attn_branch_bwd(rt, dy, dy_lp, x, g, wqkv, wproj, saved, batch, n):
+    mean, rstd, h, qkv, o, lse = saved
+    do, dwp, dbp = _linear_bwd(rt, dy_lp, o, wproj)
+    dqkv = _self_attn_bwd(rt, do, qkv, o, lse, batch, n)
+    dh, dwq, dbq = _linear_bwd(rt, dqkv, h, wqkv)
+    dx, dx_lp, dg, db = ops.layernorm_bwd(dh, x, g, mean, rstd, dx_in=dy, want_lp=not rt.exact)
+    return dx, (dx if rt.exact else dx_lp), (dg, db, dwq, dbq, dwp, dbp)
+
+
+def _patch_tokens_fwd(rt, img, pw, pb, pos, with_cls, cls=None, batch_index=None):
+    """timm PatchEmbed + pos-embed (+ cls row): returns x fp32 [B*rows, D] and the saved patch matrix."""
+    patches = ops.patchify(img, rt.patch_size, rt.act_dtype, batch_index)
+    batch = patches.shape[0] // rt.n1
+    pos2 = pos.view(rt.n2, rt.dim)
+    rows = rt.n2 if with_cls else rt.n1
+    if with_cls:
+        x = ops.gemm(patches, rt.weight(pw), epilogue=EPI_RESIDUAL, bias=pb, residual=pos2, rows_per_batch=rt.n1,
+                     out_rows_per_batch=rt.n2, row_offset=1, residual_bcast=True, out_rows=batch * rt.n2)
+        ops.write_cls_row(x.view(batch, rt.n2, rt.dim), cls.view(-1), pos2)
+    else:
+        x = ops.gemm(patches, rt.weight(pw), epilogue=EPI_RESIDUAL, bias=pb, residual=pos2[1:], rows_per_batch=rt.n1,
+                     out_rows_per_batch=rt.n1, row_offset=0, residual_bcast=True, out_rows=batch * rt.n1)
+    return x, patches, batch, rows
+
+
+def _patch_tokens_bwd(rt, dx, patches, pw, pos, with_cls, batch):
+    """dx fp32 [B*rows, D] -> (d patch weight, d patch bias, d pos_embed, d cls | None)."""
+    rows = rt.n2 if with_cls else rt.n1
+    dx3 = dx.view(batch, rows, rt.dim)
+    dpos_rows = ops.sum_rows(dx3.view(batch, rows * rt.dim)).view(rows, rt.dim)
+    dpos = torch.zeros_like(pos)
+    dcls = None
+    if with_cls:
+        dpos[0] = dpos_rows
+        dcls = dpos_rows[0].clone().view(1, 1, rt.dim)
+        dtok = ops.slice_rows_cast(dx3, 1, rt.n1, rt.act_dtype)
+    else:
+        dpos[0, 1:] = dpos_rows
+        dtok = dx if rt.exact else ops.cast(dx, rt.act_dtype)
+    dw, db = ops.linear_bwd_weight(dtok, patches)
+    return dw.view_as(pw), db, dpos, dcls
+
+
+def _bias(b):
+    return b
+
+
+# ---------------------------------------------------------------------------------------------
+# encoder: forward_first_part (vision_transformer.py:382-388)
+# ---------------------------------------------------------------------------------------------
+class EncoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rt: Runtime, img, *params):
+        pw, pb, pos = params[:3]
+        nb = len(ENC_BLOCK_KEYS)
+        blocks = [params[3 + i * nb: 3 + (i + 1) * nb] for i in range(rt.depth)]
+        grad = any(ctx.needs_input_grad)  # False under no_grad: nothing is saved for inference
+        x, patches, batch, n = _patch_tokens_fwd(rt, img, pw, _bias(pb), pos, with_cls=False)
+        tape = []
+        for P in blocks:
+            g1, b1, wqkv, bqkv, wproj, bproj, g2, b2, w1, bb1, w2, bb2 = P
+            xa, sa = _attn_branch_fwd(rt, x, g1, b1, wqkv, bqkv, wproj, bproj, batch, n)
+            xb, sm = _mlp_fwd(rt, xa, g2, b2, w1, bb1, w2, bb2)
+            if grad:
+                tape.append((x, sa, xa, sm))
+            x = xb
+        if grad:
+            ctx.rt, ctx.tape, ctx.patches, ctx.batch, ctx.params = rt, tape, patches, batch, params
+        return x.view(batch, n, rt.dim)
+
+    @staticmethod
+    def backward(ctx, dout):
+        rt, batch, n = ctx.rt, ctx.batch, ctx.rt.n1
+        params = ctx.params
+        pw, pb, pos = params[:3]
+        nb = len(ENC_BLOCK_KEYS)
+        dx = dout.contiguous().view(batch * n, rt.dim).float()
+        dx_lp = _lp(rt, dx)
+        grads = [None] * len(params)
+        for i in reversed(range(rt.depth)):
+            g1, b1, wqkv, bqkv, wproj, bproj, g2, b2, w1, bb1, w2, bb2 = params[3 + i * nb: 3 + (i + 1) * nb]
+            x, sa, xa, sm = ctx.tape[i]
+            ctx.tape[i] = None
+            dx, dx_lp, (dg2, db2, dw1, dbb1, dw2, dbb2) = _mlp_bwd(rt, dx, dx_lp, xa, g2, w1, w2, sm)
+            dx, dx_lp, (dg1, db1, dwq, dbq, dwp, dbp) = _attn_branch_bwd(rt, dx, dx_lp, x, g1, wqkv, wproj, sa, batch, n)
+            base = 3 + i * nb
+            blk = [dg1, db1, dwq, dbq if bqkv is not None else None, dwp, dbp, dg2, db2, dw1, dbb1, dw2, dbb2]
+            grads[base: base + nb] = blk
+        dpw, dpb, dpos, _ = _patch_tokens_bwd(rt, dx, ctx.patches, pw, pos, with_cls=False, batch=batch)
+        grads[0], grads[1], grads[2] = dpw, dpb, dpos
+        ctx.tape = ctx.patches = None
+        return (None, None, *grads)
+
+
+# ---------------------------------------------------------------------------------------------
+# decoder + head: forward_second_part + forward_head (vision_transformer.py:390-405,417)
+# ---------------------------------------------------------------------------------------------
+class DecoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rt: Runtime, feats, img2, *params):
+        pw, pb, pos, cls, gN, bN, wh, bh = params[:8]
+        ns = 8
+        nb = len(DEC_BLOCK_KEYS)
+        blocks = [params[ns + i * nb: ns + (i + 1) * nb] for i in range(rt.c_depth)]
+        grad = any(ctx.needs_input_grad)
+        x, patches, batch, n = _patch_tokens_fwd(rt, img2, pw, _bias(pb), pos, with_cls=True, cls=cls)
+        assert feats.shape == (batch, rt.n1, rt.dim), f'features {tuple(feats.shape)} do not match {batch} image-2 samples'
+        ctxf = feats.detach().contiguous().float().view(batch * rt.n1, rt.dim)
+        tape = []
+        d = rt.dim
+        for P in blocks:
+            g1, b1, wqkv, bqkv, wproj, bproj, gc, bc, gx, bx, wq, bq, wkv, bkv, wcp, bcp, g2, b2, w1, bb1, w2, bb2 = P
+            xa, sa = _attn_branch_fwd(rt, x, g1, b1, wqkv, bqkv, wproj, bproj, batch, n)
+            # cross attention: q from image-2 tokens, k/v from image-1 features (:174-200)
+            hq, mq, rq = ops.layernorm_fwd(xa, gc, bc, LN_EPS, rt.act_dtype)
+            hc, mc, rc = ops.layernorm_fwd(ctxf, gx, bx, LN_EPS, rt.act_dtype)
+            q = ops.gemm(hq, rt.weight(wq), bias=bq)
+            kv = ops.gemm(hc, rt.weight(wkv), bias=bkv)                      # [Mc, 2D], columns [2][h][hd] (:178)
+            kv3 = kv.view(batch, rt.n1, 2 * d)
+            oc, lse_c = ops.attention_fwd(q.view(batch, n, d), kv3[:, :, 0:d], kv3[:, :, d:2 * d], rt.heads, rt.scale)
+            oc = oc.view(batch * n, d)
+            xb = ops.gemm(oc, rt.weight(wcp), epilogue=EPI_RESIDUAL, bias=bcp, residual=xa)
+            xc, sm = _mlp_fwd(rt, xb, g2, b2, w1, bb1, w2, bb2)
+            if grad:
+                tape.append((x, sa, xa, (mq, rq, hq, mc, rc, hc, q, kv, oc, lse_c), xb, sm))
+            x = xc
+        # final norm on the cls rows only (LayerNorm is row-wise; only x[:, 0] reaches the head, :400,:417)
+        x3 = x.view(batch, n, d)
+        y, mN, rN = ops.layernorm_fwd(x3[:, 0, :], gN, bN, LN_EPS, rt.act_dtype)
+        logits = ops.gemm(y, rt.weight(wh), epilogue=EPI_STORE_F32, bias=_bias(bh))
+        if grad:
+            ctx.rt, ctx.tape, ctx.patches, ctx.batch, ctx.params = rt, tape, patches, batch, params
+            ctx.ctxf, ctx.final = ctxf, (x, y, mN, rN)
+            ctx.feats_needs_grad = feats.requires_grad
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        rt, batch, n, d = ctx.rt, ctx.batch, ctx.rt.n2, ctx.rt.dim
+        params = ctx.params
+        pw, pb, pos, cls, gN, bN, wh, bh = params[:8]
+        ns, nb = 8, len(DEC_BLOCK_KEYS)
+        grads = [None] * len(params)
+        x, y, mN, rN = ctx.final
+        # head: logits = y Wh^T + bh
+        dl = _lp(rt, dlogits.contiguous().float())
+        wh_act = rt.weight(wh)
+        dy = ops.gemm(dl, wh_act, b_layout=B_KN)                         # [B, D]
+        dwh, dbh = ops.linear_bwd_weight(dl, y)
+        # final LayerNorm touches the cls rows only; every other row of d(x) is zero
+        dx = torch.zeros((batch * n, d), dtype=torch.float32, device=dy.device)
+        dx3 = dx.view(batch, n, d)
+        dx_lp = None
+        dx_lp3 = None
+        if not rt.exact:
+            dx_lp = torch.zeros((batch * n, d), dtype=rt.act_dtype, device=dy.device)
+            dx_lp3 = dx_lp.view(batch, n, d)[:, 0, :]
+        _, _, dgN, dbN = ops.layernorm_bwd(dy, x.view(batch, n, d)[:, 0, :], gN, mN, rN, dx_out=dx3[:, 0, :],
+                                           dx_lp=dx_lp3)
+        if rt.exact:
+            dx_lp = dx
+        grads[4], grads[5], grads[6], grads[7] = dgN, dbN, dwh.view_as(wh), dbh if bh is not None else None
+        dctx = None
+        for i in reversed(range(rt.c_depth)):
+            (g1, b1, wqkv, bqkv, wproj, bproj, gc, bc, gx, bx, wq, bq, wkv, bkv, wcp, bcp, g2, b2, w1, bb1, w2,
+             bb2) = params[ns + i * nb: ns + (i + 1) * nb]
+            x, sa, xa, sc, xb, sm = ctx.tape[i]
+            ctx.tape[i] = None
+            mq, rq, hq, mc, rc, hc, q, kv, oc, lse_c = sc
+            dx, dx_lp, (dg2, db2, dw1, dbb1, dw2, dbb2) = _mlp_bwd(rt, dx, dx_lp, xb, g2, w1, w2, sm)
+            # cross attention
+            doc, dwcp, dbcp = _linear_bwd(rt, dx_lp, oc, wcp)
+            dq = torch.empty_like(q)
+            dkv = torch.empty_like(kv)
+            kv3, dkv3 = kv.view(batch, rt.n1, 2 * d), dkv.view(batch, rt.n1, 2 * d)
+            ops.attention_bwd(q.view(batch, n, d), kv3[:, :, 0:d], kv3[:, :, d:2 * d], oc.view(batch, n, d),
+                              doc.view(batch, n, d), lse_c, rt.heads, rt.scale, dq.view(batch, n, d), dkv3[:, :, 0:d],
+                              dkv3[:, :, d:2 * d])
+            dhq, dwq, dbq = _linear_bwd(rt, dq, hq, wq)
+            dhc, dwkv, dbkv = _linear_bwd(rt, dkv, hc, wkv)
+            dx, dx_lp, dgc, dbc = ops.layernorm_bwd(dhq, xa, gc, mq, rq, dx_in=dx, want_lp=not rt.exact)
+            if rt.exact:
+                dx_lp = dx
+            # d(context) accumulates over the c_depth blocks in fp32, in place
+            dctx, _, dgx, dbx = ops.layernorm_bwd(dhc, ctx.ctxf, gx, mc, rc, dx_in=dctx, dx_out=dctx)
+            dx, dx_lp, (dg1, db1, dwqkv, dbqkv, dwp, dbp) = _attn_branch_bwd(rt, dx, dx_lp, x, g1, wqkv, wproj, sa, batch, n)
+            base = ns + i * nb
+            grads[base: base + nb] = [dg1, db1, dwqkv, dbqkv if bqkv is not None else None, dwp, dbp, dgc, dbc, dgx, dbx,
+                                      dwq, dbq if bq is not None else None, dwkv, dbkv if bkv is not None else None, dwcp,
+                                      dbcp, dg2, db2, dw1, dbb1, dw2, dbb2]
+        dpw, dpb, dpos, dcls = _patch_tokens_bwd(rt, dx, ctx.patches, pw, pos, with_cls=True, batch=batch)
+        grads[0], grads[1], grads[2], grads[3] = dpw, dpb, dpos, dcls.view_as(cls)
+        dfeats = dctx.view(batch, rt.n1, d) if ctx.feats_needs_grad and dctx is not None else None
+        ctx.tape = ctx.patches = ctx.ctxf = ctx.final = None
+        return (None, dfeats, None, *grads)

@@ -1,0 +1,282 @@
+"""Functional wrappers over the C ABI: one Python function per entry point of include/vited.h.
+
+These allocate outputs (PyTorch owns every buffer), validate shape/dtype/contiguity BEFORE the
+launch and raise on any non-zero status.  They are not autograd-aware; ``functions.py`` composes
+them into the encoder / decoder autograd Functions.  Every op launches on torch's current HIP
+stream, never synchronises and never allocates on the device side, so the whole forward+backward
+is hipGraph-capturable.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from ._lib import (B_KN, B_NK, BF16, EPI_GELU, EPI_MUL_GELU_GRAD, EPI_RESIDUAL, EPI_STORE, EPI_STORE_F32, F32)
+
+_DT = {torch.float32: F32, torch.bfloat16: BF16}
+
+
+def _code(dtype: torch.dtype) -> int:
+    try:
+        return _DT[dtype]
+    except KeyError:
+        raise TypeError(f'vited ops support float32 and bfloat16 activations, got {dtype}') from None
+
+
+def _need_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError('vited ops run on the MI355X HIP kernels only: got a CPU tensor '
+                               '(there is no CPU fallback; the fp32 CPU oracle lives in oracle/ for tests)')
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _rows2d(t: torch.Tensor):
+    """(tensor, row stride) of a [rows, dim] view whose last dim is dense."""
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError(f'expected a 2-D tensor with a dense last dim, got shape {tuple(t.shape)} stride {t.stride()}')
+    return t.stride(0)
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes: int, device) -> torch.Tensor:
+    """Grow-only scratch buffer per device (fp32 elements).  Contents never outlive one op."""
+    key = (device.type, device.index)
+    buf = _ws_cache.get(key)
+    n = (int(nbytes) + 3) // 4
+    if buf is None or buf.numel() < n:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('vited workspace must be sized before graph capture: run one eager step first')
+        buf = torch.empty(max(n, 1 << 20), dtype=torch.float32, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+# ---------------------------------------------------------------------------------------------
+def cast(src: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    _need_gpu(src)
+    src = src.contiguous()
+    out = torch.empty_like(src, dtype=dtype)
+    _lib.check(_lib.load().vited_cast(_ptr(src), _code(src.dtype), _ptr(out), _code(dtype), src.numel(), _stream()), 'vited_cast')
+    return out
+
+
+def cast_transpose(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """fp32 [R, C] -> dtype [C, R] (transposed weight shadow)."""
+    _need_gpu(w)
+    assert w.dtype == torch.float32 and w.dim() == 2 and w.is_contiguous()
+    out = torch.empty((w.shape[1], w.shape[0]), dtype=dtype, device=w.device)
+    _lib.check(_lib.load().vited_cast_transpose(_ptr(w), _ptr(out), _code(dtype), w.shape[0], w.shape[1], _stream()),
+               'vited_cast_transpose')
+    return out
+
+
+def patchify(img: torch.Tensor, patch: int, dtype: torch.dtype, batch_index: torch.Tensor | None = None) -> torch.Tensor:
+    """img fp32 [B, C, S, S] (any batch stride, dense [C, S, S]) -> [B * (S/p)^2, C*p*p]."""
+    _need_gpu(img, batch_index)
+    if img.dtype != torch.float32:
+        img = img.float()
+    assert img.dim() == 4 and img.shape[2] == img.shape[3], 'expected [B, C, S, S]'
+    b, c, s, _ = img.shape
+    if img.stride()[1:] != (s * s, s, 1):
+        img = img.contiguous()
+    nb = b
+    if batch_index is not None:
+        assert batch_index.dtype == torch.int64 and batch_index.is_contiguous()
+        nb = batch_index.numel()
+    g = s // patch
+    out = torch.empty((nb * g * g, c * patch * patch), dtype=dtype, device=img.device)
+    _lib.check(_lib.load().vited_patchify(_ptr(img), img.stride(0), _ptr(batch_index), _ptr(out), _code(dtype), nb, c, s,
+                                          patch, _stream()), 'vited_patchify')
+    return out
+
+
+def slice_rows_cast(x: torch.Tensor, row_offset: int, rows: int, dtype: torch.dtype) -> torch.Tensor:
+    """fp32 [B, R, D] -> dtype [B * rows, D] taking rows [row_offset, row_offset + rows) of every batch."""
+    _need_gpu(x)
+    assert x.dtype == torch.float32 and x.dim() == 3 and x.is_contiguous()
+    b, r, d = x.shape
+    out = torch.empty((b * rows, d), dtype=dtype, device=x.device)
+    _lib.check(_lib.load().vited_slice_rows_cast(_ptr(x), _ptr(out), _code(dtype), b, r, row_offset, rows, d, _stream()),
+               'vited_slice_rows_cast')
+    return out
+
+
+def write_cls_row(x: torch.Tensor, cls: torch.Tensor, pos: torch.Tensor):
+    """x fp32 [B, R, D]: x[:, 0] = cls + pos[0]."""
+    _need_gpu(x, cls, pos)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 3
+    b, r, d = x.shape
+    _lib.check(_lib.load().vited_write_cls_row(_ptr(x), _ptr(cls), _ptr(pos), b, r, d, _stream()), 'vited_write_cls_row')
+
+
+def sum_rows(x: torch.Tensor) -> torch.Tensor:
+    """[batch, width] (fp32 or bf16, dense rows) -> fp32 [width] column sums, deterministic."""
+    _need_gpu(x)
+    ld = _rows2d(x)
+    b, w = x.shape
+    lib = _lib.load()
+    out = torch.empty(w, dtype=torch.float32, device=x.device)
+    nbytes = lib.vited_sum_rows_workspace_bytes(b, w)
+    ws = workspace(nbytes, x.device)
+    _lib.check(lib.vited_sum_rows(_ptr(x), _code(x.dtype), ld, _ptr(out), b, w, _ptr(ws), ws.numel() * 4, _stream()),
+               'vited_sum_rows')
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, out_dtype: torch.dtype):
+    """x fp32 [rows, dim] (row-strided ok) -> (y [rows, dim] out_dtype, mean, rstd)."""
+    _need_gpu(x, gamma, beta)
+    assert x.dtype == torch.float32 and gamma.dtype == torch.float32 and beta.dtype == torch.float32
+    ld = _rows2d(x)
+    rows, dim = x.shape
+    y = torch.empty((rows, dim), dtype=out_dtype, device=x.device)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().vited_layernorm_fwd(_ptr(x), ld, _ptr(gamma), _ptr(beta), _ptr(y), _code(out_dtype), dim,
+                                               _ptr(mean), _ptr(rstd), rows, dim, float(eps), _stream()), 'vited_layernorm_fwd')
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dx_in=None, dx_out=None, want_lp: bool = False, dx_lp=None):
+    """Returns (dx fp32, dx_lp bf16 | None, dgamma, dbeta).
+
+    dx = (dx_in or 0) + LN'(dy).  ``dx_out`` / ``dx_lp`` may be given as pre-made (row-strided)
+    destinations - e.g. the cls rows of a zero-filled token-gradient tensor."""
+    _need_gpu(dy, x, gamma, mean, rstd, dx_in, dx_out, dx_lp)
+    dy_ld, x_ld = _rows2d(dy), _rows2d(x)
+    rows, dim = x.shape
+    assert dy.shape == x.shape and x.dtype == torch.float32
+    lib = _lib.load()
+    if dx_out is None:
+        dx_out = torch.empty((rows, dim), dtype=torch.float32, device=x.device)
+    if want_lp and dx_lp is None:
+        dx_lp = torch.empty((rows, dim), dtype=torch.bfloat16, device=x.device)
+    if dx_in is not None:
+        assert dx_in.dtype == torch.float32 and dx_in.shape == x.shape
+    dgamma = torch.empty(dim, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty(dim, dtype=torch.float32, device=x.device)
+    nbytes = lib.vited_layernorm_bwd_workspace_bytes(rows, dim)
+    ws = workspace(nbytes, x.device)
+    _lib.check(lib.vited_layernorm_bwd(
+        _ptr(dy), _code(dy.dtype), dy_ld, _ptr(x), x_ld, _ptr(gamma), _ptr(mean), _ptr(rstd),
+        _ptr(dx_in), _rows2d(dx_in) if dx_in is not None else 0, _ptr(dx_out), _rows2d(dx_out),
+        _ptr(dx_lp), BF16, _rows2d(dx_lp) if dx_lp is not None else 0, _ptr(dgamma), _ptr(dbeta), rows, dim,
+        _ptr(ws), ws.numel() * 4, _stream()), 'vited_layernorm_bwd')
+    return dx_out, dx_lp, dgamma, dbeta
+
+
+# ---------------------------------------------------------------------------------------------
+def gemm(a: torch.Tensor, b: torch.Tensor, *, b_layout: int = B_NK, epilogue: int = EPI_STORE, bias=None, aux=None,
+         residual=None, out=None, rows_per_batch: int = 0, out_rows_per_batch: int = 0, row_offset: int = 0,
+         residual_bcast: bool = False, out_rows: int | None = None):
+    """acc = a[M,K] . (b[N,K]^T | b[K,N]); see VITED_EPI_* in include/vited.h.
+
+    Returns ``out`` (and ``out2`` for EPI_GELU)."""
+    _need_gpu(a, b, bias, aux, residual, out)
+    assert a.dtype == b.dtype, f'operand dtypes differ: {a.dtype} vs {b.dtype}'
+    lda, ldb = _rows2d(a), _rows2d(b)
+    m, k = a.shape
+    n = b.shape[0] if b_layout == B_NK else b.shape[1]
+    kb = b.shape[1] if b_layout == B_NK else b.shape[0]
+    if kb != k:
+        raise ValueError(f'contraction mismatch: A is [{m},{k}], B gives K={kb}')
+    f32_out = epilogue in (EPI_RESIDUAL, EPI_STORE_F32)
+    if out is None:
+        rows = m if out_rows is None else out_rows
+        out = torch.empty((rows, n), dtype=torch.float32 if f32_out else a.dtype, device=a.device)
+    ldo = _rows2d(out)
+    out2 = None
+    if epilogue == EPI_GELU:
+        out2 = torch.empty_like(out)
+    if aux is not None:
+        assert aux.dtype == a.dtype and _rows2d(aux) == ldo
+    if residual is not None:
+        assert residual.dtype == torch.float32 and residual.stride(-1) == 1
+        assert residual.stride(-2) == ldo if residual.dim() >= 2 else True
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.numel() == n
+    _lib.check(_lib.load().vited_gemm(
+        _ptr(a), lda, _ptr(b), ldb, b_layout, _code(a.dtype), m, n, k, epilogue, _ptr(bias), _ptr(aux), _ptr(residual),
+        _ptr(out), _ptr(out2), ldo, rows_per_batch, out_rows_per_batch, row_offset, int(bool(residual_bcast)), _stream()),
+        'vited_gemm')
+    return (out, out2) if epilogue == EPI_GELU else out
+
+
+def linear_bwd_weight(dy: torch.Tensor, x: torch.Tensor, want_bias: bool = True):
+    """dW[N,K] = dy[M,N]^T x[M,K] (fp32), dbias[N] = column sums of dy (fp32) or None."""
+    _need_gpu(dy, x)
+    assert dy.dtype == x.dtype and dy.shape[0] == x.shape[0]
+    lddy, ldx = _rows2d(dy), _rows2d(x)
+    m, n = dy.shape
+    k = x.shape[1]
+    lib = _lib.load()
+    dw = torch.empty((n, k), dtype=torch.float32, device=x.device)
+    db = torch.empty(n, dtype=torch.float32, device=x.device) if want_bias else None
+    nbytes = lib.vited_linear_bwd_weight_workspace_bytes(m, n, k)
+    ws = workspace(nbytes, x.device)
+    _lib.check(lib.vited_linear_bwd_weight(_ptr(dy), lddy, _ptr(x), ldx, _code(x.dtype), m, n, k, _ptr(dw), _ptr(db),
+                                           _ptr(ws), ws.numel() * 4, _stream()), 'vited_linear_bwd_weight')
+    return dw, db
+
+
+# ---------------------------------------------------------------------------------------------
+def _head_view(t: torch.Tensor, heads: int, head_dim: int):
+    """t is [B, N, heads*head_dim] (a last-dim slice of the packed projection): (ptr-holder, bs, ts)."""
+    assert t.dim() == 3 and t.stride(2) == 1 and t.shape[2] == heads * head_dim
+    return t.stride(0), t.stride(1)
+
+
+def attention_fwd(q, k, v, heads: int, scale: float):
+    """q [B,Nq,D], k/v [B,Nk,D] (strided views of the packed qkv / kv projections are fine)
+    -> (o [B,Nq,D] contiguous, lse fp32 [B,H,Nq])."""
+    _need_gpu(q, k, v)
+    b, nq, d = q.shape
+    nk = k.shape[1]
+    hd = d // heads
+    assert q.dtype == k.dtype == v.dtype and k.shape == v.shape and k.shape[0] == b and k.shape[2] == d
+    q_bs, q_ts = _head_view(q, heads, hd)
+    k_bs, k_ts = _head_view(k, heads, hd)
+    v_bs, v_ts = _head_view(v, heads, hd)
+    o = torch.empty((b, nq, d), dtype=q.dtype, device=q.device)
+    lse = torch.empty((b, heads, nq), dtype=torch.float32, device=q.device)
+    _lib.check(_lib.load().vited_attention_fwd(_ptr(q), q_bs, q_ts, _ptr(k), k_bs, k_ts, _ptr(v), v_bs, v_ts, _ptr(o),
+                                               nq * d, d, _ptr(lse), _code(q.dtype), b, heads, nq, nk, hd, float(scale),
+                                               _stream()), 'vited_attention_fwd')
+    return o, lse
+
+
+def attention_bwd(q, k, v, o, do, lse, heads: int, scale: float, dq, dk, dv):
+    """Writes dq/dk/dv (pre-allocated, same strided conventions as q/k/v)."""
+    _need_gpu(q, k, v, o, do, lse, dq, dk, dv)
+    b, nq, d = q.shape
+    nk = k.shape[1]
+    hd = d // heads
+    assert o.is_contiguous() and do.is_contiguous() and o.dtype == do.dtype == q.dtype
+    q_bs, q_ts = _head_view(q, heads, hd)
+    k_bs, k_ts = _head_view(k, heads, hd)
+    v_bs, v_ts = _head_view(v, heads, hd)
+    dq_bs, dq_ts = _head_view(dq, heads, hd)
+    dk_bs, dk_ts = _head_view(dk, heads, hd)
+    dv_bs, dv_ts = _head_view(dv, heads, hd)
+    delta = torch.empty((b, heads, nq), dtype=torch.float32, device=q.device)
+    _lib.check(_lib.load().vited_attention_bwd(
+        _ptr(q), q_bs, q_ts, _ptr(k), k_bs, k_ts, _ptr(v), v_bs, v_ts, _ptr(o), _ptr(do), nq * d, d, _ptr(lse), _ptr(delta),
+        _ptr(dq), dq_bs, dq_ts, _ptr(dk), dk_bs, dk_ts, _ptr(dv), dv_bs, dv_ts, _code(q.dtype), b, heads, nq, nk, hd,
+        float(scale), _stream()), 'vited_attention_bwd')
+    return dq, dk, dv
+
+
+def last_paths():
+    lib = _lib.load()
+    return lib.vited_last_gemm_path(), lib.vited_last_attention_path()
