@@ -6,9 +6,11 @@
 Tolerances
   * fp32 kernels ("exact" path): rtol 1e-3 on logits - the tolerance BASELINE.json's north_star
     states - and rtol 2e-3 on per-parameter gradient norms (measured error is ~1e-5).
-  * bf16 MFMA path: logits within 3e-2 (abs + rel), gradient norms within 5 %.  For scale: PyTorch's
-    own CPU bf16-autocast of the reference deviates by up to 8e-3 abs on logits of magnitude 0.4
-    (SURVEY.md section 7), so rtol 1e-3 is not a bf16 tolerance for anybody.
+  * bf16 MFMA path: logits within 3e-2 (abs + rel).  For scale: PyTorch's own CPU bf16-autocast of
+    the reference deviates by up to 8e-3 abs on logits of magnitude 0.4, so rtol
+    1e-3 is not a bf16 tolerance for anybody.  bf16 GRADIENTS are judged against that same yardstick
+    (see _check_bf16_grads_like_torch_autocast) on the closed-form fixtures, and at 6 % per tensor on
+    the well-conditioned reference-style random init.
 """
 import os
 
@@ -72,11 +74,13 @@ def test_against_reference_fixtures(vited, gpu, name, dtype):
     grads = dict(model.named_parameters())
     names = [str(n) for n in fx['grad_names']]
     assert names == [n for n, _ in model.named_parameters()]
-    got = np.array([float(grads[n].grad.double().norm()) for n in names])
     want = fx['grad_norms']
-    gt = dict(rtol=2e-3, atol=1e-6) if exact else dict(rtol=5e-2, atol=2e-3 * float(want.max()))
-    np.testing.assert_allclose(got, want, **gt)
-    st = dict(rtol=2e-3, atol=1e-5 * float(want.max())) if exact else dict(rtol=1e-1, atol=2e-3 * float(want.max()))
+    if not exact:
+        _check_bf16_grads_like_torch_autocast(s, batch, {n: grads[n].grad.cpu() for n in names})
+        return
+    got = np.array([float(grads[n].grad.double().norm()) for n in names])
+    np.testing.assert_allclose(got, want, rtol=2e-3, atol=1e-6)
+    st = dict(rtol=2e-3, atol=1e-5 * float(want.max()))
     np.testing.assert_allclose(grads['head.weight'].grad.cpu().numpy(), fx['grad_head_weight'], **st)
     np.testing.assert_allclose(grads['cls_token'].grad.cpu().numpy(), fx['grad_cls_token'], **st)
     np.testing.assert_allclose(grads['pos_embed'].grad[0, :3, :16].cpu().numpy(), fx['grad_pos_embed_slice'], **st)
@@ -85,27 +89,86 @@ def test_against_reference_fixtures(vited, gpu, name, dtype):
                                fx['grad_kv0_slice'], **st)
 
 
+def _oracle_grads(s, batch, autocast):
+    m = vo.fill_closed_form_(vo.OracleViTED(s))
+    x = vo.closed_form_pairs(batch, s)
+    y = (vo.closed_form((batch, s.num_classes), 77, 1.0) > 0.2).float()
+    with torch.autocast('cpu', dtype=torch.bfloat16, enabled=autocast):
+        out = m(x)
+    torch.nn.functional.binary_cross_entropy_with_logits(out.float(), y).backward()
+    return {n: p.grad for n, p in m.named_parameters()}
+
+
+def _check_bf16_grads_like_torch_autocast(s, batch, g_hip):
+    """bf16 gradients on the closed-form fixtures are ill-conditioned for EVERY bf16 implementation
+    (PyTorch's own CPU bf16 autocast of the oracle is off by > 100 % on some tensors), so the
+    yardstick for the MFMA path is that autocast run: the HIP path must be about as close to the
+    fp32 gradients as PyTorch bf16 autocast is - globally within 1.5x (+1e-2), per tensor within
+    3x (+5e-2).  The 8+8-block closed-form case is chaotic in bf16 (two bf16 implementations differ
+    from each other as much as from fp32), so there only a 4x global bound is asserted; the
+    well-conditioned full-depth check is test_against_oracle_random_init[8-*]."""
+    g32 = _oracle_grads(s, batch, autocast=False)
+    gac = _oracle_grads(s, batch, autocast=True)
+
+    def total(g):
+        num = sum(float((g[n].double() - g32[n].double()).norm() ** 2) for n in g32)
+        den = sum(float(g32[n].double().norm() ** 2) for n in g32)
+        return (num / den) ** 0.5
+
+    t_hip, t_ac = total(g_hip), total(gac)
+    deep = s.depth + s.c_depth >= 8
+    assert t_hip <= (4.0 if deep else 1.5) * t_ac + 1e-2, f'global bf16 gradient error {t_hip:.3e} vs torch autocast {t_ac:.3e}'
+    if deep:
+        return
+    for n in g32:
+        den = float(g32[n].norm()) + 1e-12
+        e_hip = float((g_hip[n] - g32[n]).norm()) / den
+        e_ac = float((gac[n] - g32[n]).norm()) / den
+        assert e_hip <= 3 * e_ac + 5e-2, f'{n}: HIP bf16 error {e_hip:.3e}, torch bf16 autocast error {e_ac:.3e}'
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
-def test_against_oracle_random_init(vited, gpu, dtype):
-    """Reference-style random init + seeded gaussian pairs, config A at depth 2+2, batch 8."""
+@pytest.mark.parametrize('depth', [2, 8])
+def test_against_oracle_random_init(vited, gpu, dtype, depth):
+    """Reference-style random init (timm init on the encoder side, PyTorch default on the decoder) +
+    seeded gaussian pairs, config A at depth 2+2 and at the full 8+8, batch 8.  Well conditioned, so
+    tolerances are tight: fp32 kernels rtol 1e-3 on logits and 1e-3 per gradient tensor (measured
+    ~1e-6); bf16 MFMA path 3e-2 on logits, 5e-2 per gradient tensor, 2e-2 globally, and never worse
+    than 1.5x what PyTorch's own CPU bf16 autocast of the oracle gives."""
     torch.manual_seed(0)
-    s = vo.ViTEDShape(depth=2, c_depth=2)
+    s = vo.ViTEDShape(depth=depth, c_depth=depth)
     oracle = vo.OracleViTED(s)
     model = _hip_model(vited, s, gpu, dtype)
     model.load_state_dict(oracle.state_dict())
     x = torch.randn(8, 2, 3, 64, 64).clamp(-1, 1)
     y = (torch.rand(8, 4) > 0.75).float()
-    lo = oracle(x)
-    torch.nn.functional.binary_cross_entropy_with_logits(lo, y).backward()
+
+    def oracle_run(autocast):
+        oracle.zero_grad()
+        with torch.autocast('cpu', dtype=torch.bfloat16, enabled=autocast):
+            out = oracle(x)
+        torch.nn.functional.binary_cross_entropy_with_logits(out.float(), y).backward()
+        return out.detach().float(), {n: p.grad.clone() for n, p in oracle.named_parameters()}
+
+    lo, g32 = oracle_run(False)
     lh = model(x.to(gpu))
     torch.nn.functional.binary_cross_entropy_with_logits(lh, y.to(gpu)).backward()
+    gh = {n: p.grad.cpu() for n, p in model.named_parameters()}
     exact = dtype == torch.float32
-    torch.testing.assert_close(lh.cpu(), lo.detach(), **(dict(rtol=1e-3, atol=1e-5) if exact else dict(rtol=3e-2, atol=3e-2)))
-    og = dict(oracle.named_parameters())
-    for n, p in model.named_parameters():
-        ref = og[n].grad
-        err = (p.grad.cpu() - ref).norm() / (ref.norm() + 1e-12)
-        assert err < (1e-3 if exact else 6e-2), f'{n}: relative gradient error {err:.3e}'
+    torch.testing.assert_close(lh.detach().cpu(), lo, **(dict(rtol=1e-3, atol=1e-5) if exact else dict(rtol=3e-2, atol=3e-2)))
+
+    def total(g):
+        num = sum(float((g[n].double() - g32[n].double()).norm() ** 2) for n in g32)
+        return (num / sum(float(g32[n].double().norm() ** 2) for n in g32)) ** 0.5
+
+    for n in g32:
+        err = float((gh[n] - g32[n]).norm() / (g32[n].norm() + 1e-12))
+        assert err < (1e-3 if exact else 5e-2), f'{n}: relative gradient error {err:.3e}'
+    if exact:
+        assert total(gh) < 1e-4
+    else:
+        _, gac = oracle_run(True)
+        assert total(gh) < 2e-2 and total(gh) <= 1.5 * total(gac) + 1e-3, (total(gh), total(gac))
 
 
 def test_train_equals_eval_and_no_grad_saves_nothing(vited, gpu):
