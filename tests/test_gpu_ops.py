@@ -216,6 +216,8 @@ def test_attention_fwd_bwd(vited, gpu, dtype, B, H, Nq, Nk, hd):
         kv = _rand((B, Nk, 2 * D), gpu, 2, dtype=dtype)
         k, v = kv[:, :, :D], kv[:, :, D:]
     o, lse = ops.attention_fwd(q, k, v, H, scale)
+    small = dtype == torch.bfloat16 and Nk <= 80 and Nq <= 80
+    assert ops.last_paths()[1] == (2 if small else 1)          # bf16 short sequences run the MFMA kernel
     qr, kr, vr = (t.double().clone().requires_grad_() for t in (q, k, v))
     o_ref, lse_ref = _sdpa_ref(qr, kr, vr, H, scale)
     tol = dict(rtol=1e-4, atol=1e-5) if dtype == torch.float32 else BF16_OUT
@@ -231,6 +233,7 @@ def test_attention_fwd_bwd(vited, gpu, dtype, B, H, Nq, Nk, hd):
         dk, dv = dkv[:, :, :D], dkv[:, :, D:]
     # the kernels consume the SAVED (storage-dtype) output o, like the reference's SDPA backward
     ops.attention_bwd(q, k, v, o, do, lse, H, scale, dq, dk, dv)
+    assert ops.last_paths()[1] == (2 if (small and hd == 32) else 1)
     btol = dict(rtol=2e-4, atol=2e-5) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2)
     torch.testing.assert_close(dq.double(), qr.grad, **btol)
     torch.testing.assert_close(dk.double(), kr.grad, **btol)

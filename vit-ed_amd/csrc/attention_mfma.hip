@@ -1,7 +1,382 @@
-// bf16 MFMA attention kernels (placeholder until the tiled kernels land: reports "unsupported" so the
-// dispatcher uses the portable kernels).
+// bf16 MFMA attention for short sequences (Nq, Nk <= 80 tokens: BASELINE config A has 64 / 65),
+// head_dim 32 or 64.  One 64-lane wave owns one (batch, head); a workgroup's 4 waves take 4
+// adjacent heads of the same batch element so that their 64/128-byte head slices of each token row
+// share cache lines.  HBM-bound by design (the scores never leave registers):
+//
+//   forward :  S^T = K Q^T   (v_mfma_f32_16x16x32_bf16, keys on accumulator rows, queries on lanes)
+//              softmax over keys = over a lane's registers + 2 cross-lane shuffles (no LDS)
+//              O^T = V^T P^T : P^T is already the B operand in registers (a consistent permutation
+//              of the key index inside each 32-key MFMA step makes the accumulator layout legal);
+//              V^T comes from a wave-private, XOR-swizzled LDS image read with ds_read_b64_tr_b16.
+//   backward:  both orientations of the scores are recomputed from Q, K and the saved LSE
+//              (S^T for dQ, S for dK / dV) so every product contracts over an accumulator-row
+//              index; Q, K, dO are staged once in LDS for the transposed operand reads.
+//
+// Rows beyond Nq / Nk are clamped on load (finite data), masked to -inf / 0 in the softmax and never
+// stored.
 #include "attention_kernels.h"
 
-bool attention_mfma_supported(const AttnArgs&, bool) { return false; }
-int attention_fwd_mfma(const AttnArgs&, hipStream_t) { return VITED_ERR_UNSUPPORTED; }
-int attention_bwd_mfma(const AttnArgs&, hipStream_t) { return VITED_ERR_UNSUPPORTED; }
+#define SM_MAX_TILES 5  // 5 x 16 = 80 tokens
+
+__device__ __forceinline__ bf16x4 tr_read4(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p);
+}
+
+template <int HD> struct SmallCfg {
+    static constexpr int ROW_BYTES = HD * 2;          // one token's head slice
+    static constexpr int KCH = HD / 32;               // 32-wide k-steps of a q.k dot product
+    static constexpr int DT = HD / 16;                // 16-wide tiles of the head dim
+    static constexpr int TILE_BYTES = (SM_MAX_TILES + 1) * 16 * ROW_BYTES;  // +1: zero phantom tile of an odd last k-step
+    // XOR on the 32-byte slot index so the 8 rows x 32 B a half-wave reads per tr-read hit 64 distinct banks
+    __device__ static __forceinline__ int swz(int r) { return HD == 32 ? ((r >> 2) & 1) << 5 : ((r >> 1) & 3) << 5; }
+    __device__ static __forceinline__ int off(int r, int byte_in_row) { return r * ROW_BYTES + (byte_in_row ^ swz(r)); }
+};
+
+// 16-row x HD tile -> registers in MFMA row-fragment form (lane: row fr, 8 elements at 8*(g + 4*c)),
+// rows clamped to n-1.
+template <int HD>
+__device__ __forceinline__ void load_row_frags(const bf16* base, int64_t ts, int row0, int n, int fr, int g,
+                                               bf16x8 (&f)[HD / 32]) {
+    int r = row0 + fr;
+    r = r < n ? r : n - 1;
+#pragma unroll
+    for (int c = 0; c < HD / 32; ++c) f[c] = *(const bf16x8*)(base + (int64_t)r * ts + 8 * (g + 4 * c));
+}
+
+template <int HD>
+__device__ __forceinline__ void stage_tile(char* lds, int row0, int n, int fr, int g, const bf16x8 (&f)[HD / 32]) {
+    const int r = row0 + fr;
+#pragma unroll
+    for (int c = 0; c < HD / 32; ++c) {
+        bf16x8 v = f[c];
+        if (r >= n) v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        *(bf16x8*)(lds + SmallCfg<HD>::off(r, 16 * (g + 4 * c))) = v;
+    }
+}
+
+// transposed operand: 16 (head-dim) x 32 (token) fragment for k-step ks of tile image `lds`, with the
+// in-step token order (4g..4g+3 of the even tile, then 4g..4g+3 of the odd tile) that matches an
+// accumulator pair used as the other operand.
+template <int HD>
+__device__ __forceinline__ bf16x8 tr_frag(const char* lds, int ks, int dt, int g, int qq, int p) {
+    const int r0 = 32 * ks + 4 * g + qq, r1 = r0 + 16;
+    const bf16x4 lo = tr_read4(lds + SmallCfg<HD>::off(r0, dt * 32 + 8 * p));
+    const bf16x4 hi = tr_read4(lds + SmallCfg<HD>::off(r1, dt * 32 + 8 * p));
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+__device__ __forceinline__ bf16x8 pack_pair(const f32x4& a, const f32x4& b) {
+    return bf16x8{(bf16)a[0], (bf16)a[1], (bf16)a[2], (bf16)a[3], (bf16)b[0], (bf16)b[1], (bf16)b[2], (bf16)b[3]};
+}
+
+__device__ __forceinline__ float group_max4(float v) {  // over the 4 lanes that share lane & 15
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float group_sum4(float v) {
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+}
+
+#define LOG2E 1.4426950408889634f
+#define LN2 0.6931471805599453f
+
+template <int HD, int NKT>
+__global__ void __launch_bounds__(256)
+attn_fwd_small_kernel(AttnArgs a) {
+    using C = SmallCfg<HD>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fr = lane & 15, g = lane >> 4, qq = fr >> 2, p = fr & 3;
+    const int64_t b = blockIdx.x;
+    int h = blockIdx.y * 4 + wave;
+    const bool live = h < a.heads;
+    h = live ? h : a.heads - 1;
+    const int nq = (int)a.nq, nk = (int)a.nk;
+    const bf16* qb = (const bf16*)a.q + b * a.q_bs + (int64_t)h * HD;
+    const bf16* kb = (const bf16*)a.k + b * a.k_bs + (int64_t)h * HD;
+    const bf16* vb = (const bf16*)a.v + b * a.v_bs + (int64_t)h * HD;
+    char* vs = smem + wave * C::TILE_BYTES;
+
+    bf16x8 kf[NKT][C::KCH];
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) {
+        load_row_frags<HD>(kb, a.k_ts, 16 * t, nk, fr, g, kf[t]);
+        bf16x8 vf[C::KCH];
+        load_row_frags<HD>(vb, a.v_ts, 16 * t, nk, fr, g, vf);
+        stage_tile<HD>(vs, 16 * t, nk, fr, g, vf);
+    }
+    if (NKT & 1) {  // the odd last k-step reads a phantom tile: keep it finite (zeros)
+        const bf16x8 z[C::KCH] = {};
+        stage_tile<HD>(vs, 16 * NKT, 0, fr, g, z);
+    }
+    __syncthreads();
+    const float sc = a.scale * LOG2E;
+    const int nqt = (nq + 15) >> 4;
+    for (int i = 0; i < nqt; ++i) {
+        bf16x8 qf[C::KCH];
+        load_row_frags<HD>(qb, a.q_ts, 16 * i, nq, fr, g, qf);
+        f32x4 st[NKT + 1];
+        float m = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < NKT; ++t) {
+            f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < C::KCH; ++c) s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][c], qf[c], s, 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s[e] = (16 * t + 4 * g + e) < nk ? s[e] * sc : -INFINITY;
+                m = fmaxf(m, s[e]);
+            }
+            st[t] = s;
+        }
+        st[NKT] = f32x4{0.f, 0.f, 0.f, 0.f};
+        m = group_max4(m);
+        float l = 0.f;
+#pragma unroll
+        for (int t = 0; t < NKT; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float pe = exp2f(st[t][e] - m);
+                st[t][e] = pe;
+                l += pe;
+            }
+        l = group_sum4(l);
+        const float inv = 1.f / l;
+        const int q = 16 * i + fr;
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt) {
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < (NKT + 1) / 2; ++ks) {
+                const bf16x8 vt = tr_frag<HD>(vs, ks, dt, g, qq, p);
+                o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt, pack_pair(st[2 * ks], st[2 * ks + 1]), o, 0, 0, 0);
+            }
+            if (live && q < nq) {
+                const bf16x4 ov = {(bf16)(o[0] * inv), (bf16)(o[1] * inv), (bf16)(o[2] * inv), (bf16)(o[3] * inv)};
+                *(bf16x4*)((bf16*)a.o + b * a.o_bs + (int64_t)q * a.o_ts + (int64_t)h * HD + dt * 16 + 4 * g) = ov;
+            }
+        }
+        if (live && g == 0 && q < nq) a.lse[(b * a.heads + h) * a.nq + q] = (m + log2f(l)) * LN2;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward, Nq and Nk <= 80.  LDS per wave: K, Q, dO images (transposed-operand reads) + lse/delta.
+//   phase T (per query tile i; keys on accumulator rows, queries on lanes):
+//       S^T = K Q_i^T, dP^T = V dO_i^T, dS^T = P^T o (dP^T - delta) -> dQ_i^T = K^T dS^T  (tr-read K)
+//   phase N (per key tile t; queries on accumulator rows, keys on lanes):
+//       S = Q K_t^T, dP = dO V_t^T -> dV_t^T = dO^T P (tr-read dO), dK_t^T = Q^T dS (tr-read Q)
+// ------------------------------------------------------------------------------------------------
+template <int HD, int NQT, int NKT>
+__global__ void __launch_bounds__(256)
+attn_bwd_small_kernel(AttnArgs a) {
+    using C = SmallCfg<HD>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int STAT_BYTES = (SM_MAX_TILES + 1) * 16 * 4;
+    constexpr int WAVE_BYTES = 3 * C::TILE_BYTES + 2 * STAT_BYTES;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fr = lane & 15, g = lane >> 4, qq = fr >> 2, p = fr & 3;
+    const int64_t b = blockIdx.x;
+    int h = blockIdx.y * 4 + wave;
+    const bool live = h < a.heads;
+    h = live ? h : a.heads - 1;
+    const int nq = (int)a.nq, nk = (int)a.nk;
+    const int64_t hoff = (int64_t)h * HD;
+    const bf16* qb = (const bf16*)a.q + b * a.q_bs + hoff;
+    const bf16* kb = (const bf16*)a.k + b * a.k_bs + hoff;
+    const bf16* vb = (const bf16*)a.v + b * a.v_bs + hoff;
+    const bf16* ob = (const bf16*)a.o + b * a.o_bs + hoff;
+    const bf16* dob = (const bf16*)a.d_o + b * a.o_bs + hoff;
+    char* k_s = smem + wave * WAVE_BYTES;
+    char* q_s = k_s + C::TILE_BYTES;
+    char* do_s = q_s + C::TILE_BYTES;
+    float* lse_s = (float*)(do_s + C::TILE_BYTES);
+    float* del_s = lse_s + (SM_MAX_TILES + 1) * 16;
+    const float sc = a.scale * LOG2E;
+
+    bf16x8 kf[NKT][C::KCH], vf[NKT][C::KCH], qf[NQT][C::KCH], dof[NQT][C::KCH];
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) {
+        load_row_frags<HD>(kb, a.k_ts, 16 * t, nk, fr, g, kf[t]);
+        load_row_frags<HD>(vb, a.v_ts, 16 * t, nk, fr, g, vf[t]);
+        stage_tile<HD>(k_s, 16 * t, nk, fr, g, kf[t]);
+    }
+#pragma unroll
+    for (int i = 0; i < NQT; ++i) {
+        load_row_frags<HD>(qb, a.q_ts, 16 * i, nq, fr, g, qf[i]);
+        load_row_frags<HD>(dob, a.o_ts, 16 * i, nq, fr, g, dof[i]);
+        stage_tile<HD>(q_s, 16 * i, nq, fr, g, qf[i]);
+        stage_tile<HD>(do_s, 16 * i, nq, fr, g, dof[i]);
+        // delta[q] = sum_d O[q][d] dO[q][d]; lse in log2 units
+        bf16x8 of[C::KCH];
+        load_row_frags<HD>(ob, a.o_ts, 16 * i, nq, fr, g, of);
+        float dl = 0.f;
+#pragma unroll
+        for (int c = 0; c < C::KCH; ++c)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dl = fmaf((float)of[c][e], (float)dof[i][c][e], dl);
+        dl = group_sum4(dl);
+        const int q = 16 * i + fr;
+        if (g == 0) {
+            del_s[q] = dl;
+            lse_s[q] = a.lse[(b * a.heads + h) * a.nq + (q < nq ? q : nq - 1)] * LOG2E;
+        }
+    }
+    {
+        const bf16x8 z[C::KCH] = {};
+        if (NKT & 1) stage_tile<HD>(k_s, 16 * NKT, 0, fr, g, z);
+        if (NQT & 1) {
+            stage_tile<HD>(q_s, 16 * NQT, 0, fr, g, z);
+            stage_tile<HD>(do_s, 16 * NQT, 0, fr, g, z);
+        }
+    }
+    __syncthreads();
+
+    // ---- phase T: dQ -------------------------------------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < NQT; ++i) {
+        const int q = 16 * i + fr;
+        const float lse2 = lse_s[q], dl = del_s[q];
+        f32x4 ds[NKT + 1];
+#pragma unroll
+        for (int t = 0; t < NKT; ++t) {
+            f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < C::KCH; ++c) {
+                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][c], qf[i][c], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[t][c], dof[i][c], dp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float pe = (16 * t + 4 * g + e) < nk ? exp2f(s[e] * sc - lse2) : 0.f;
+                ds[t][e] = pe * (dp[e] - dl);
+            }
+        }
+        ds[NKT] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < (NKT + 1) / 2; ++ks)
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<HD>(k_s, ks, dt, g, qq, p),
+                                                              pack_pair(ds[2 * ks], ds[2 * ks + 1]), acc, 0, 0, 0);
+            if (live && q < nq) {
+                const bf16x4 ov = {(bf16)(acc[0] * a.scale), (bf16)(acc[1] * a.scale), (bf16)(acc[2] * a.scale), (bf16)(acc[3] * a.scale)};
+                *(bf16x4*)((bf16*)a.dq + b * a.dq_bs + (int64_t)q * a.dq_ts + hoff + dt * 16 + 4 * g) = ov;
+            }
+        }
+    }
+
+    // ---- phase N: dK, dV ---------------------------------------------------------------------------
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) {
+        f32x4 pr[NQT + 1], ds[NQT + 1];
+#pragma unroll
+        for (int i = 0; i < NQT; ++i) {
+            f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < C::KCH; ++c) {
+                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[i][c], kf[t][c], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof[i][c], vf[t][c], dp, 0, 0, 0);
+            }
+            const f32x4 l4 = *(const f32x4*)(lse_s + 16 * i + 4 * g);
+            const f32x4 d4 = *(const f32x4*)(del_s + 16 * i + 4 * g);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float pe = (16 * i + 4 * g + e) < nq ? exp2f(s[e] * sc - l4[e]) : 0.f;
+                pr[i][e] = pe;
+                ds[i][e] = pe * (dp[e] - d4[e]);
+            }
+        }
+        pr[NQT] = f32x4{0.f, 0.f, 0.f, 0.f};
+        ds[NQT] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int key = 16 * t + fr;
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt) {
+            f32x4 av = {0.f, 0.f, 0.f, 0.f}, ak = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int qs = 0; qs < (NQT + 1) / 2; ++qs) {
+                av = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<HD>(do_s, qs, dt, g, qq, p),
+                                                             pack_pair(pr[2 * qs], pr[2 * qs + 1]), av, 0, 0, 0);
+                ak = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<HD>(q_s, qs, dt, g, qq, p),
+                                                             pack_pair(ds[2 * qs], ds[2 * qs + 1]), ak, 0, 0, 0);
+            }
+            if (live && key < nk) {
+                const bf16x4 vv = {(bf16)av[0], (bf16)av[1], (bf16)av[2], (bf16)av[3]};
+                const bf16x4 kk = {(bf16)(ak[0] * a.scale), (bf16)(ak[1] * a.scale), (bf16)(ak[2] * a.scale), (bf16)(ak[3] * a.scale)};
+                *(bf16x4*)((bf16*)a.dv + b * a.dv_bs + (int64_t)key * a.dv_ts + hoff + dt * 16 + 4 * g) = vv;
+                *(bf16x4*)((bf16*)a.dk + b * a.dk_bs + (int64_t)key * a.dk_ts + hoff + dt * 16 + 4 * g) = kk;
+            }
+        }
+    }
+}
+
+bool attention_mfma_supported(const AttnArgs& a, bool backward) {
+    auto al = [](const void* p, int n) { return ((uintptr_t)p % n) == 0; };
+    if (backward) {
+        if (a.head_dim != 32 || a.nq > 16 * SM_MAX_TILES) return false;
+        if (a.dq_ts % 4 || a.dk_ts % 4 || a.dv_ts % 4 || a.dq_bs % 4 || a.dk_bs % 4 || a.dv_bs % 4) return false;
+        if (a.o_ts % 8 || a.o_bs % 8 || !al(a.o, 16) || !al(a.d_o, 16) || !al(a.dq, 8) || !al(a.dk, 8) || !al(a.dv, 8)) return false;
+    }
+    if (a.head_dim != 32 && a.head_dim != 64) return false;
+    if (a.nk > 16 * SM_MAX_TILES || a.nq > 65535) return false;
+    if (a.q_ts % 8 || a.k_ts % 8 || a.v_ts % 8 || a.q_bs % 8 || a.k_bs % 8 || a.v_bs % 8 || a.o_ts % 4 || a.o_bs % 4) return false;
+    if (!al(a.q, 16) || !al(a.k, 16) || !al(a.v, 16) || !al(a.o, 8)) return false;
+    return true;
+}
+
+template <int HD>
+static int launch_fwd_small(const AttnArgs& a, hipStream_t s) {
+    const int nkt = (int)((a.nk + 15) / 16);
+    dim3 grid((unsigned)a.batch, (unsigned)((a.heads + 3) / 4));
+    const size_t lds = 4 * SmallCfg<HD>::TILE_BYTES;
+#define L(N) hipLaunchKernelGGL((attn_fwd_small_kernel<HD, N>), grid, dim3(256), lds, s, a)
+    switch (nkt) {
+        case 1: L(1); break;
+        case 2: L(2); break;
+        case 3: L(3); break;
+        case 4: L(4); break;
+        case 5: L(5); break;
+        default: return VITED_ERR_UNSUPPORTED;
+    }
+#undef L
+    return vited_check_launch();
+}
+
+int attention_fwd_mfma(const AttnArgs& a, hipStream_t s) {
+    if (a.head_dim == 32) return launch_fwd_small<32>(a, s);
+    if (a.head_dim == 64) return launch_fwd_small<64>(a, s);
+    return VITED_ERR_UNSUPPORTED;
+}
+
+template <int NQT>
+static int launch_bwd_small32(const AttnArgs& a, int nkt, hipStream_t s) {
+    dim3 grid((unsigned)a.batch, (unsigned)((a.heads + 3) / 4));
+    const size_t lds = 4 * (3 * SmallCfg<32>::TILE_BYTES + 2 * (SM_MAX_TILES + 1) * 16 * 4);
+#define L(N) hipLaunchKernelGGL((attn_bwd_small_kernel<32, NQT, N>), grid, dim3(256), lds, s, a)
+    switch (nkt) {
+        case 1: L(1); break;
+        case 2: L(2); break;
+        case 3: L(3); break;
+        case 4: L(4); break;
+        case 5: L(5); break;
+        default: return VITED_ERR_UNSUPPORTED;
+    }
+#undef L
+    return vited_check_launch();
+}
+
+int attention_bwd_mfma(const AttnArgs& a, hipStream_t s) {
+    const int nqt = (int)((a.nq + 15) / 16), nkt = (int)((a.nk + 15) / 16);
+    switch (nqt) {
+        case 1: return launch_bwd_small32<1>(a, nkt, s);
+        case 2: return launch_bwd_small32<2>(a, nkt, s);
+        case 3: return launch_bwd_small32<3>(a, nkt, s);
+        case 4: return launch_bwd_small32<4>(a, nkt, s);
+        case 5: return launch_bwd_small32<5>(a, nkt, s);
+        default: return VITED_ERR_UNSUPPORTED;
+    }
+}

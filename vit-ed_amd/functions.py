@@ -57,7 +57,7 @@ class Runtime:
         w2 = w.detach().reshape(w.shape[0], -1)
         if self.exact:
             return w2
-        return self._cached(w, 'n', lambda: ops.cast(w2, self.act_dtype))
+        return self._cached(w, 'n', lambda out=None: ops.cast(w2, self.act_dtype, out=out))
 
     def weight_t(self, w: torch.Tensor):
         """Operand + layout of the input-gradient GEMM dX = dY . W: the transposed bf16 shadow (NT
@@ -65,16 +65,15 @@ class Runtime:
         w2 = w.detach().reshape(w.shape[0], -1)
         if self.exact:
             return w2, B_KN
-        return self._cached(w, 't', lambda: ops.cast_transpose(w2.contiguous(), self.act_dtype)), B_NK
+        return self._cached(w, 't', lambda out=None: ops.cast_transpose(w2.contiguous(), self.act_dtype, out=out)), B_NK
 
     def _cached(self, w, tag, make):
         key = (id(w), tag)
         ent = self._shadow.get(key)
         if ent is None or ent[0] != w._version or ent[1] != w.data_ptr():
-            if torch.cuda.is_current_stream_capturing() and ent is not None:
-                # refresh IN PLACE so a captured graph keeps reading the same buffer
-                ent[2].copy_(make())
-                ent = (w._version, w.data_ptr(), ent[2])
+            if ent is not None and ent[1] == w.data_ptr():
+                # refresh IN PLACE: a captured graph keeps reading the same shadow buffer
+                ent = (w._version, w.data_ptr(), make(ent[2]))
             else:
                 ent = (w._version, w.data_ptr(), make())
             self._shadow[key] = ent
@@ -88,8 +87,10 @@ class Runtime:
             if p is None:
                 continue
             w2 = p.detach().reshape(p.shape[0], -1)
-            fresh = ops.cast(w2, self.act_dtype) if tag == 'n' else ops.cast_transpose(w2.contiguous(), self.act_dtype)
-            ent[2].copy_(fresh)
+            if tag == 'n':
+                ops.cast(w2, self.act_dtype, out=ent[2])
+            else:
+                ops.cast_transpose(w2.contiguous(), self.act_dtype, out=ent[2])
             self._shadow[(pid, tag)] = (p._version, p.data_ptr(), ent[2])
 
 

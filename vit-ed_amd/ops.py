@@ -62,19 +62,23 @@ def workspace(nbytes: int, device) -> torch.Tensor:
 
 
 # ---------------------------------------------------------------------------------------------
-def cast(src: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
-    _need_gpu(src)
+def cast(src: torch.Tensor, dtype: torch.dtype, out: torch.Tensor | None = None) -> torch.Tensor:
+    _need_gpu(src, out)
     src = src.contiguous()
-    out = torch.empty_like(src, dtype=dtype)
+    if out is None:
+        out = torch.empty_like(src, dtype=dtype)
+    assert out.dtype == dtype and out.numel() == src.numel() and out.is_contiguous()
     _lib.check(_lib.load().vited_cast(_ptr(src), _code(src.dtype), _ptr(out), _code(dtype), src.numel(), _stream()), 'vited_cast')
     return out
 
 
-def cast_transpose(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+def cast_transpose(w: torch.Tensor, dtype: torch.dtype, out: torch.Tensor | None = None) -> torch.Tensor:
     """fp32 [R, C] -> dtype [C, R] (transposed weight shadow)."""
-    _need_gpu(w)
+    _need_gpu(w, out)
     assert w.dtype == torch.float32 and w.dim() == 2 and w.is_contiguous()
-    out = torch.empty((w.shape[1], w.shape[0]), dtype=dtype, device=w.device)
+    if out is None:
+        out = torch.empty((w.shape[1], w.shape[0]), dtype=dtype, device=w.device)
+    assert out.dtype == dtype and out.shape == (w.shape[1], w.shape[0]) and out.is_contiguous()
     _lib.check(_lib.load().vited_cast_transpose(_ptr(w), _ptr(out), _code(dtype), w.shape[0], w.shape[1], _stream()),
                'vited_cast_transpose')
     return out
