@@ -145,13 +145,11 @@ def main():
     from vited_amd import engine
     V._lib.load()
 
-    cfg = V.config_from_yaml(args.cfg) if rank == 0 else None
-    if world > 1:
-        box = [cfg]
-        dist.broadcast_object_list(box, src=0)
-        cfg = box[0]
-    torch.manual_seed(cfg.SEED + rank)          # misc/engine.py:28
-    model = V.build_model(cfg).to(dev)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):   # the reference's loaders print; stdout carries only the JSON line
+        cfg = V.config_from_yaml(args.cfg)
+        torch.manual_seed(cfg.SEED + rank)          # misc/engine.py:28
+        model = V.build_model(cfg).to(dev)
     model.compute_dtype = torch.float32 if args.fp32 else torch.bfloat16
     engine.broadcast_parameters(model)
     B, S, C = args.batch, cfg.DATA.IMG_SIZE, cfg.MODEL.NUM_CLASSES

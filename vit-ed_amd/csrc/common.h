@@ -44,6 +44,32 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
     return cdf + x * pdf;
 }
 
+// Cheap erf-GELU for the bf16 MFMA epilogues (the libm erff above costs more VALU time than the
+// K=384 GEMM it follows): Abramowitz-Stegun 7.1.26, |erf error| <= 1.5e-7, i.e. far below one bf16
+// ulp; one v_exp_f32 + one v_rcp_f32 + 7 FMAs, and gelu' reuses the same exponential because
+// exp(-(x/sqrt2)^2) is also the Gaussian density's exponent.
+__device__ __forceinline__ void gelu_parts_fast(float x, float& cdf, float& e) {
+    const float u = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, u, 1.0f));
+    e = __builtin_amdgcn_exp2f(-u * u * 1.4426950408889634f);  // exp(-x^2/2)
+    float p = fmaf(t, 1.061405429f, -1.453152027f);
+    p = fmaf(t, p, 1.421413741f);
+    p = fmaf(t, p, -0.284496736f);
+    p = fmaf(t, p, 0.254829592f);
+    const float half_erfc = 0.5f * p * t * e;            // 0.5 * (1 - erf(|x|/sqrt2))
+    cdf = x >= 0.f ? 1.0f - half_erfc : half_erfc;
+}
+__device__ __forceinline__ float gelu_fast(float x) {
+    float cdf, e;
+    gelu_parts_fast(x, cdf, e);
+    return x * cdf;
+}
+__device__ __forceinline__ float gelu_grad_fast(float x) {
+    float cdf, e;
+    gelu_parts_fast(x, cdf, e);
+    return fmaf(x * 0.39894228040143268f, e, cdf);
+}
+
 static inline int vited_check_launch() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? VITED_OK : VITED_ERR_LAUNCH;

@@ -52,7 +52,7 @@ static inline int64_t max64(int64_t a, int64_t b) { return a > b ? a : b; }
 extern "C" int64_t vited_linear_bwd_weight_workspace_bytes(int64_t M, int64_t N, int64_t K) {
     const int64_t s = max64(tn_portable_splits(M, N, K), gemm_tn_mfma_splits(M, N, K));
     // slabs for dW + the row-sum workspace for dbias (placed after the slabs)
-    return (s * N * K) * (int64_t)sizeof(float) + vited_sum_rows_workspace_bytes(M, N) + 256;
+    return (s * N * K + s * N) * (int64_t)sizeof(float) + vited_sum_rows_workspace_bytes(M, N) + 256;
 }
 
 extern "C" int vited_linear_bwd_weight(const void* dY, int64_t lddy, const void* X, int64_t ldx, int dtype, int64_t M,
@@ -68,7 +68,14 @@ extern "C" int vited_linear_bwd_weight(const void* dY, int64_t lddy, const void*
     int rc;
     if (mfma) {
         g_last_gemm_path = 2;
-        rc = gemm_tn_mfma(dY, lddy, X, ldx, M, N, K, splits, slab, s);
+        float* bias_slab = !dbias ? nullptr : (splits > 1 ? workspace + splits * N * K : dbias);
+        rc = gemm_tn_mfma(dY, lddy, X, ldx, M, N, K, splits, slab, bias_slab, s);
+        if (rc != VITED_OK) return rc;
+        if (splits > 1) {
+            rc = sum_rows_f32_single_pass(workspace, N * K, dW, splits, N * K, s);
+            if (rc == VITED_OK && dbias) rc = sum_rows_f32_single_pass(bias_slab, N, dbias, splits, N, s);
+        }
+        return rc;
     } else {
         g_last_gemm_path = 1;
         rc = gemm_tn_portable(dY, lddy, X, ldx, dtype, M, N, K, splits, slab, s);

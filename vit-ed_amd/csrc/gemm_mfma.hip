@@ -1,7 +1,8 @@
 // bf16 MFMA GEMM kernels for gfx950 (CDNA4), the contraction engine of the ViT-ED path.
 //
 //  gemm_nt_mfma_kernel : out = epilogue(A[M,K] . B[N,K]^T)        (Linear fwd, and dX via W^T shadow)
-//  gemm_tn_mfma_kernel : dW[N,K] = sum_m dY[m,N]^T X[m,K], split over M into fp32 slabs
+//  gemm_tn_mfma_kernel : dW[N,K] = sum_m dY[m,N]^T X[m,K] (+ dbias[N] = sum_m dY[m,N]),
+//                        split over M into fp32 slabs that a small pass sums (deterministic)
 //
 // Both: 256 threads = 4 waves (2 x 2), 128 x 128 output tile, each wave 64 x 64 = 4 x 4
 // v_mfma_f32_16x16x32_bf16 accumulators; operands staged global -> LDS with 16-byte
@@ -9,7 +10,9 @@
 // stage's DMA in flight under the current stage's MFMAs.  LDS images are XOR-swizzled on the
 // SOURCE address (the DMA destination is lane-linear) with the matching XOR on the read, so the
 // ds_read_b128 / ds_read_b64_tr_b16 fragment reads are bank-conflict free.
-// The NT epilogue is staged through LDS so every global access is a 16-byte, row-contiguous one.
+// The NT epilogue is staged through LDS so every global access is a 16-byte, row-contiguous one, and
+// the epilogue operands that do not depend on the accumulators (residual rows, saved pre-activation,
+// bias) are fetched BEFORE the main loop so their HBM latency hides under the MFMAs.
 #include "gemm_kernels.h"
 
 #define BM 128
@@ -51,32 +54,66 @@ __device__ __forceinline__ void nt_stage_load(const bf16* __restrict__ A, int64_
     }
 }
 
+// operands of the epilogue that can be fetched before the accumulators exist (one output row slice
+// of 16 columns per lane and per 16-row sub-tile i)
+template <int EPI> struct EpiPrefetch {
+    f32x4 res[EPI == VITED_EPI_RESIDUAL ? 4 : 1][4];
+    bf16x8 aux[EPI == VITED_EPI_MUL_GELU_GRAD ? 4 : 1][2];
+    f32x4 bias[4];
+    int64_t orow[EPI == VITED_EPI_RESIDUAL ? 4 : 1];
+};
+
 template <int EPI>
-__device__ __forceinline__ void epilogue_store16(const EpiParams& p, int64_t m, int64_t n, float* v) {
-    if (p.bias) {
+__device__ __forceinline__ void epilogue_prefetch(const EpiParams& p, EpiPrefetch<EPI>& pf, int64_t mbase, int64_t n, int64_t M,
+                                                  int64_t N) {
+    const bool ncol = n < N;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 b = *(const f32x4*)(p.bias + n + q * 4);
+    for (int q = 0; q < 4; ++q) pf.bias[q] = (p.bias && ncol) ? *(const f32x4*)(p.bias + n + q * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (EPI == VITED_EPI_RESIDUAL) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[q * 4 + e] += b[e];
+        for (int i = 0; i < 4; ++i) {
+            const int64_t m = mbase + i * 16;
+            int64_t orow = m, rrow = m;
+            if (p.rows_per_batch > 0) {
+                const int64_t b = m / p.rows_per_batch, r = m - b * p.rows_per_batch + p.row_offset;
+                orow = b * p.out_rows_per_batch + r;
+                rrow = p.residual_bcast ? r : orow;
+            }
+            pf.orow[i] = orow;
+            const bool ok = m < M && ncol;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                pf.res[i][q] = ok ? *(const f32x4*)(p.residual + rrow * p.ldo + n + q * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
+    if constexpr (EPI == VITED_EPI_MUL_GELU_GRAD) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t m = mbase + i * 16;
+            const bool ok = m < M && ncol;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                pf.aux[i][h] = ok ? *(const bf16x8*)((const bf16*)p.aux + m * p.ldo + n + h * 8) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    }
+}
+
+template <int EPI>
+__device__ __forceinline__ void epilogue_store16(const EpiParams& p, const EpiPrefetch<EPI>& pf, int i, int64_t m, int64_t n,
+                                                 float* v) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[q * 4 + e] += pf.bias[q][e];
     if constexpr (EPI == VITED_EPI_STORE_F32) {
         float* o = (float*)p.out + m * p.ldo + n;
 #pragma unroll
         for (int q = 0; q < 4; ++q) *(f32x4*)(o + q * 4) = f32x4{v[q * 4], v[q * 4 + 1], v[q * 4 + 2], v[q * 4 + 3]};
     } else if constexpr (EPI == VITED_EPI_RESIDUAL) {
-        int64_t orow = m, rrow = m;
-        if (p.rows_per_batch > 0) {
-            const int64_t b = m / p.rows_per_batch, r = m - b * p.rows_per_batch + p.row_offset;
-            orow = b * p.out_rows_per_batch + r;
-            rrow = p.residual_bcast ? r : orow;
-        }
-        const float* res = p.residual + rrow * p.ldo + n;
-        float* o = (float*)p.out + orow * p.ldo + n;
+        float* o = (float*)p.out + pf.orow[i] * p.ldo + n;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            f32x4 r4 = *(const f32x4*)(res + q * 4);
+            f32x4 r4 = pf.res[i][q];
 #pragma unroll
             for (int e = 0; e < 4; ++e) r4[e] += v[q * 4 + e];
             *(f32x4*)(o + q * 4) = r4;
@@ -84,13 +121,10 @@ __device__ __forceinline__ void epilogue_store16(const EpiParams& p, int64_t m, 
     } else {
         bf16* o = (bf16*)p.out + m * p.ldo + n;
         if constexpr (EPI == VITED_EPI_MUL_GELU_GRAD) {
-            const bf16* z = (const bf16*)p.aux + m * p.ldo + n;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const bf16x8 zz = *(const bf16x8*)(z + h * 8);
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[h * 8 + e] *= gelu_grad_f((float)zz[e]);
-            }
+                for (int e = 0; e < 8; ++e) v[h * 8 + e] *= gelu_grad_fast((float)pf.aux[i][h][e]);
         }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -105,7 +139,7 @@ __device__ __forceinline__ void epilogue_store16(const EpiParams& p, int64_t m, 
             for (int h = 0; h < 2; ++h) {
                 bf16x8 pk;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) pk[e] = (bf16)gelu_f(v[h * 8 + e]);
+                for (int e = 0; e < 8; ++e) pk[e] = (bf16)gelu_fast(v[h * 8 + e]);
                 *(bf16x8*)(o2 + h * 8) = pk;
             }
         }
@@ -132,6 +166,10 @@ gemm_nt_mfma_kernel(const bf16* __restrict__ A, int64_t lda, const bf16* __restr
     const int nk = (int)(K / BK);
     nt_stage_load(A, lda, B, ldb, m0, n0, M, N, 0, smem, wave, lane);
     const int fr = lane & 15, fq = lane >> 4;
+    const int erow = lane >> 2, ecol = (lane & 3) * 16;
+    const int64_t em = m0 + wr * 64 + erow, en = n0 + wc * 64 + ecol;
+    EpiPrefetch<EPI> pf;
+    epilogue_prefetch<EPI>(ep, pf, em, en, M, N);
     for (int t = 0; t < nk; ++t) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();  // stage t landed for every wave; everyone is done reading stage t-1
@@ -156,7 +194,6 @@ gemm_nt_mfma_kernel(const bf16* __restrict__ A, int64_t lda, const bf16* __restr
     // ---- epilogue: accumulators -> per-wave LDS scratch -> 16 contiguous columns per lane ----------
     __syncthreads();
     float* sc = (float*)(smem + wave * SCRATCH_BYTES);
-    const int erow = lane >> 2, ecol = (lane & 3) * 16;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -171,8 +208,8 @@ gemm_nt_mfma_kernel(const bf16* __restrict__ A, int64_t lda, const bf16* __restr
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[q * 4 + e] = t4[e];
         }
-        const int64_t m = m0 + wr * 64 + i * 16 + erow, n = n0 + wc * 64 + ecol;
-        if (m < M && n < N) epilogue_store16<EPI>(ep, m, n, v);
+        const int64_t m = em + i * 16;
+        if (m < M && en < N) epilogue_store16<EPI>(ep, pf, i, m, en, v);
         __syncthreads();
     }
 }
@@ -214,6 +251,9 @@ int gemm_nt_mfma(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t
 // TN (weight gradient): stage = dY tile [64 m][128 n] + X tile [64 m][128 k], 256-byte rows.
 // Image (b) of the guide's dual-use layouts: chunk ch of row r lives at ch ^ (((r&3)<<2)|((r>>2)&3));
 // both MFMA operands are read column-wise with ds_read_b64_tr_b16.
+// The bias gradient rides along: the workgroups of the first k-tile column multiply their dY
+// fragments by an all-ones B operand (4 extra MFMAs per 32 rows, on one wave column), which leaves
+// sum_m dY[m, n] in every column of a 16 x 16 accumulator.
 // ================================================================================================
 #define TM 64
 #define T_TILE_BYTES (TM * 128 * 2)
@@ -244,9 +284,10 @@ __device__ __forceinline__ void tn_stage_load(const bf16* __restrict__ dY, int64
     }
 }
 
+template <bool BIAS>
 __global__ void __launch_bounds__(256)
 gemm_tn_mfma_kernel(const bf16* __restrict__ dY, int64_t lddy, const bf16* __restrict__ X, int64_t ldx, int64_t M, int64_t N,
-                    int64_t K, int64_t rows_per_split, int tiles_k, float* __restrict__ out) {
+                    int64_t K, int64_t rows_per_split, int tiles_k, float* __restrict__ out, float* __restrict__ bias_out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -255,12 +296,17 @@ gemm_tn_mfma_kernel(const bf16* __restrict__ dY, int64_t lddy, const bf16* __res
     const int64_t mb = (int64_t)blockIdx.y * rows_per_split;
     int64_t me = mb + rows_per_split;
     me = me < M ? me : M;
+    const bool do_bias = BIAS && kc0 == 0 && wc == 0;  // wave-uniform
 
-    f32x4 acc[4][4];
+    f32x4 acc[4][4], accb[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i) {
+        accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const bf16 one = (bf16)1.0f;
+    const bf16x8 ones = {one, one, one, one, one, one, one, one};
 
     const int nsteps = me > mb ? (int)((me - mb + TM - 1) / TM) : 0;
     if (nsteps > 0) tn_stage_load(dY, lddy, X, ldx, mb, me - 1, n0, N, kc0, K, smem, wave, lane);
@@ -309,6 +355,10 @@ gemm_tn_mfma_kernel(const bf16* __restrict__ dY, int64_t lddy, const bf16* __res
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf_[j], acc[i][j], 0, 0, 0);
+            if (do_bias) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, accb[i], 0, 0, 0);
+            }
         }
     }
     float* o = out + (int64_t)blockIdx.y * N * K;
@@ -325,6 +375,16 @@ gemm_tn_mfma_kernel(const bf16* __restrict__ dY, int64_t lddy, const bf16* __res
             }
         }
     }
+    if (do_bias && fr == 0) {
+        float* bo = bias_out + (int64_t)blockIdx.y * N;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int64_t n = n0 + wr * 64 + i * 16 + fq * 4 + e;
+                if (n < N) bo[n] = accb[i][e];
+            }
+    }
 }
 
 bool gemm_tn_mfma_supported(const void* dY, int64_t lddy, const void* X, int64_t ldx, int64_t M, int64_t N, int64_t K) {
@@ -332,9 +392,11 @@ bool gemm_tn_mfma_supported(const void* dY, int64_t lddy, const void* X, int64_t
     return N % 8 == 0 && K % 8 == 0 && N >= 8 && K >= 8 && lddy % 8 == 0 && ldx % 8 == 0 && al16(dY) && al16(X) && M >= 1;
 }
 
+// Splits over M: as many as fill the chip's 512 resident workgroup slots (2 per CU at 64 KB of LDS)
+// in ONE round - one workgroup more than a round costs a whole extra round.
 int64_t gemm_tn_mfma_splits(int64_t M, int64_t N, int64_t K) {
     const int64_t tiles = ceil_div64(N, 128) * ceil_div64(K, 128);
-    int64_t s = ceil_div64(512, tiles);
+    int64_t s = 512 / tiles;
     const int64_t max_s = ceil_div64(M, 512);
     if (s > max_s) s = max_s;
     if (s < 1) s = 1;
@@ -343,11 +405,15 @@ int64_t gemm_tn_mfma_splits(int64_t M, int64_t N, int64_t K) {
 }
 
 int gemm_tn_mfma(const void* dY, int64_t lddy, const void* X, int64_t ldx, int64_t M, int64_t N, int64_t K, int64_t splits,
-                 float* out, hipStream_t s) {
+                 float* out, float* bias_out, hipStream_t s) {
     const int tiles_k = (int)ceil_div64(K, 128);
     const int tiles = (int)ceil_div64(N, 128) * tiles_k;
     const int64_t rps = ceil_div64(ceil_div64(M, splits), TM) * TM;
-    hipLaunchKernelGGL(gemm_tn_mfma_kernel, dim3(tiles, (unsigned)splits), dim3(256), 2 * T_STAGE_BYTES, s, (const bf16*)dY, lddy,
-                       (const bf16*)X, ldx, M, N, K, rps, tiles_k, out);
+    if (bias_out)
+        hipLaunchKernelGGL((gemm_tn_mfma_kernel<true>), dim3(tiles, (unsigned)splits), dim3(256), 2 * T_STAGE_BYTES, s,
+                           (const bf16*)dY, lddy, (const bf16*)X, ldx, M, N, K, rps, tiles_k, out, bias_out);
+    else
+        hipLaunchKernelGGL((gemm_tn_mfma_kernel<false>), dim3(tiles, (unsigned)splits), dim3(256), 2 * T_STAGE_BYTES, s,
+                           (const bf16*)dY, lddy, (const bf16*)X, ldx, M, N, K, rps, tiles_k, out, bias_out);
     return vited_check_launch();
 }
