@@ -13,15 +13,28 @@
 // The NT epilogue is staged through LDS so every global access is a 16-byte, row-contiguous one, and
 // the epilogue operands that do not depend on the accumulators (residual rows, saved pre-activation,
 // bias) are fetched BEFORE the main loop so their HBM latency hides under the MFMAs.
+#include <stdlib.h>
+
 #include "gemm_kernels.h"
+#include "gemm_nt_epilogue.h"
 
 #define BM 128
 #define BN 128
-#define BK 64
-#define A_BYTES (BM * BK * 2)
-#define STAGE_BYTES (A_BYTES + BN * BK * 2)
-#define SCRATCH_LD 68  // floats per row of the per-wave epilogue scratch (16 rows)
-#define SCRATCH_BYTES (16 * SCRATCH_LD * 4)
+// K-step depth per LDS stage: 64 (2 stages = 64 KB, 2 workgroups per CU) for long contractions,
+// 32 (2 stages = 32 KB, 4 workgroups per CU) for K <= 512 where a tile's life is only a few steps and
+// occupancy, not pipeline depth, is what hides HBM latency.
+template <int BKT> struct NtCfg {
+    static constexpr int ROW_BYTES = BKT * 2;
+    static constexpr int A_BYTES = BM * ROW_BYTES;
+    static constexpr int STAGE_BYTES = A_BYTES + BN * ROW_BYTES;
+    static constexpr int ROWS_PER_DMA = 1024 / ROW_BYTES;   // one global_load_lds wave-instruction = 1 KiB
+    static constexpr int CHUNKS = ROW_BYTES / 16;
+    // chunk c of row r lives at c ^ swz(r): every ds_read_b128 lane group then covers all 64 banks
+    __device__ static __forceinline__ int swz(int r) {
+        return BKT == 64 ? ((r >> 1) & 7) : ((0x78 >> (2 * ((r >> 2) & 3))) & 3);
+    }
+    __device__ static __forceinline__ int off(int r, int c) { return r * ROW_BYTES + ((c ^ swz(r)) << 4); }
+};
 
 __device__ __forceinline__ void glds16(const void* g, void* l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -34,119 +47,27 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
-// ---- NT: [rows][64 bf16] tiles, 128-byte rows, chunk c of row r lives at c ^ ((r >> 1) & 7) ------
-__device__ __forceinline__ int nt_off(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
-
+// ---- NT stage: A tile [128 rows][BKT bf16] then B tile, each wave DMAs 32 rows of both ---------------
+template <int BKT>
 __device__ __forceinline__ void nt_stage_load(const bf16* __restrict__ A, int64_t lda, const bf16* __restrict__ B,
                                               int64_t ldb, int64_t m0, int64_t n0, int64_t M, int64_t N, int64_t k0,
                                               char* stage, int wave, int lane) {
-    const int rsub = lane >> 3, cp = lane & 7;
+    using C = NtCfg<BKT>;
+    const int rsub = lane / C::CHUNKS, cp = lane % C::CHUNKS;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = wave * 32 + i * 8 + rsub;
-        const int c = cp ^ ((r >> 1) & 7);
+    for (int i = 0; i < 32 / C::ROWS_PER_DMA; ++i) {
+        const int r = wave * 32 + i * C::ROWS_PER_DMA + rsub;
+        const int c = cp ^ C::swz(r);
         int64_t gm = m0 + r;
         gm = gm < M ? gm : M - 1;
         int64_t gn = n0 + r;
         gn = gn < N ? gn : N - 1;
-        glds16(A + gm * lda + k0 + c * 8, stage + (wave * 32 + i * 8) * 128);
-        glds16(B + gn * ldb + k0 + c * 8, stage + A_BYTES + (wave * 32 + i * 8) * 128);
+        glds16(A + gm * lda + k0 + c * 8, stage + (wave * 32 + i * C::ROWS_PER_DMA) * C::ROW_BYTES);
+        glds16(B + gn * ldb + k0 + c * 8, stage + C::A_BYTES + (wave * 32 + i * C::ROWS_PER_DMA) * C::ROW_BYTES);
     }
 }
 
-// operands of the epilogue that can be fetched before the accumulators exist (one output row slice
-// of 16 columns per lane and per 16-row sub-tile i)
-template <int EPI> struct EpiPrefetch {
-    f32x4 res[EPI == VITED_EPI_RESIDUAL ? 4 : 1][4];
-    bf16x8 aux[EPI == VITED_EPI_MUL_GELU_GRAD ? 4 : 1][2];
-    f32x4 bias[4];
-    int64_t orow[EPI == VITED_EPI_RESIDUAL ? 4 : 1];
-};
-
-template <int EPI>
-__device__ __forceinline__ void epilogue_prefetch(const EpiParams& p, EpiPrefetch<EPI>& pf, int64_t mbase, int64_t n, int64_t M,
-                                                  int64_t N) {
-    const bool ncol = n < N;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) pf.bias[q] = (p.bias && ncol) ? *(const f32x4*)(p.bias + n + q * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-    if constexpr (EPI == VITED_EPI_RESIDUAL) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int64_t m = mbase + i * 16;
-            int64_t orow = m, rrow = m;
-            if (p.rows_per_batch > 0) {
-                const int64_t b = m / p.rows_per_batch, r = m - b * p.rows_per_batch + p.row_offset;
-                orow = b * p.out_rows_per_batch + r;
-                rrow = p.residual_bcast ? r : orow;
-            }
-            pf.orow[i] = orow;
-            const bool ok = m < M && ncol;
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                pf.res[i][q] = ok ? *(const f32x4*)(p.residual + rrow * p.ldo + n + q * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-    }
-    if constexpr (EPI == VITED_EPI_MUL_GELU_GRAD) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int64_t m = mbase + i * 16;
-            const bool ok = m < M && ncol;
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-                pf.aux[i][h] = ok ? *(const bf16x8*)((const bf16*)p.aux + m * p.ldo + n + h * 8) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-        }
-    }
-}
-
-template <int EPI>
-__device__ __forceinline__ void epilogue_store16(const EpiParams& p, const EpiPrefetch<EPI>& pf, int i, int64_t m, int64_t n,
-                                                 float* v) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[q * 4 + e] += pf.bias[q][e];
-    if constexpr (EPI == VITED_EPI_STORE_F32) {
-        float* o = (float*)p.out + m * p.ldo + n;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) *(f32x4*)(o + q * 4) = f32x4{v[q * 4], v[q * 4 + 1], v[q * 4 + 2], v[q * 4 + 3]};
-    } else if constexpr (EPI == VITED_EPI_RESIDUAL) {
-        float* o = (float*)p.out + pf.orow[i] * p.ldo + n;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            f32x4 r4 = pf.res[i][q];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) r4[e] += v[q * 4 + e];
-            *(f32x4*)(o + q * 4) = r4;
-        }
-    } else {
-        bf16* o = (bf16*)p.out + m * p.ldo + n;
-        if constexpr (EPI == VITED_EPI_MUL_GELU_GRAD) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[h * 8 + e] *= gelu_grad_fast((float)pf.aux[i][h][e]);
-        }
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            bf16x8 pk;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) pk[e] = (bf16)v[h * 8 + e];
-            *(bf16x8*)(o + h * 8) = pk;
-        }
-        if constexpr (EPI == VITED_EPI_GELU) {
-            bf16* o2 = (bf16*)p.out2 + m * p.ldo + n;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                bf16x8 pk;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) pk[e] = (bf16)gelu_fast(v[h * 8 + e]);
-                *(bf16x8*)(o2 + h * 8) = pk;
-            }
-        }
-    }
-}
-
-template <int EPI>
+template <int EPI, int BKT>
 __global__ void __launch_bounds__(256)
 gemm_nt_mfma_kernel(const bf16* __restrict__ A, int64_t lda, const bf16* __restrict__ B, int64_t ldb, int64_t M, int64_t N,
                     int64_t K, int tiles_n, int ntiles, EpiParams ep) {
@@ -163,27 +84,27 @@ gemm_nt_mfma_kernel(const bf16* __restrict__ A, int64_t lda, const bf16* __restr
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = (int)(K / BK);
-    nt_stage_load(A, lda, B, ldb, m0, n0, M, N, 0, smem, wave, lane);
+    using C = NtCfg<BKT>;
+    const int nk = (int)(K / BKT);
+    nt_stage_load<BKT>(A, lda, B, ldb, m0, n0, M, N, 0, smem, wave, lane);
     const int fr = lane & 15, fq = lane >> 4;
-    const int erow = lane >> 2, ecol = (lane & 3) * 16;
-    const int64_t em = m0 + wr * 64 + erow, en = n0 + wc * 64 + ecol;
+    const int64_t mtile = m0 + wr * 64, ntile = n0 + wc * 64;
     EpiPrefetch<EPI> pf;
-    epilogue_prefetch<EPI>(ep, pf, em, en, M, N);
+    epilogue_prefetch<EPI>(ep, pf, mtile, ntile, M, N, lane);
     for (int t = 0; t < nk; ++t) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();  // stage t landed for every wave; everyone is done reading stage t-1
         if (t + 1 < nk)
-            nt_stage_load(A, lda, B, ldb, m0, n0, M, N, (int64_t)(t + 1) * BK, smem + ((t + 1) & 1) * STAGE_BYTES, wave, lane);
-        const char* sa = smem + (t & 1) * STAGE_BYTES;
-        const char* sb = sa + A_BYTES;
+            nt_stage_load<BKT>(A, lda, B, ldb, m0, n0, M, N, (int64_t)(t + 1) * BKT, smem + ((t + 1) & 1) * C::STAGE_BYTES, wave, lane);
+        const char* sa = smem + (t & 1) * C::STAGE_BYTES;
+        const char* sb = sa + C::A_BYTES;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+        for (int kk = 0; kk < BKT / 32; ++kk) {
             bf16x8 af[4], bf_[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8*)(sa + nt_off(wr * 64 + i * 16 + fr, kk * 4 + fq));
+            for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8*)(sa + C::off(wr * 64 + i * 16 + fr, kk * 4 + fq));
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bf_[j] = *(const bf16x8*)(sb + nt_off(wc * 64 + j * 16 + fr, kk * 4 + fq));
+            for (int j = 0; j < 4; ++j) bf_[j] = *(const bf16x8*)(sb + C::off(wc * 64 + j * 16 + fr, kk * 4 + fq));
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -191,7 +112,7 @@ gemm_nt_mfma_kernel(const bf16* __restrict__ A, int64_t lda, const bf16* __restr
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf_[j], acc[i][j], 0, 0, 0);
         }
     }
-    // ---- epilogue: accumulators -> per-wave LDS scratch -> 16 contiguous columns per lane ----------
+    // ---- epilogue: accumulators -> per-wave LDS scratch -> full-line row segments (gemm_nt_epilogue.h)
     __syncthreads();
     float* sc = (float*)(smem + wave * SCRATCH_BYTES);
 #pragma unroll
@@ -201,15 +122,7 @@ gemm_nt_mfma_kernel(const bf16* __restrict__ A, int64_t lda, const bf16* __restr
 #pragma unroll
             for (int e = 0; e < 4; ++e) sc[(fq * 4 + e) * SCRATCH_LD + j * 16 + fr] = acc[i][j][e];
         __syncthreads();
-        float v[16];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 t4 = *(const f32x4*)(sc + erow * SCRATCH_LD + ecol + q * 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[q * 4 + e] = t4[e];
-        }
-        const int64_t m = em + i * 16;
-        if (m < M && en < N) epilogue_store16<EPI>(ep, pf, i, m, en, v);
+        epilogue_subtile<EPI>(ep, pf, sc, i, mtile, ntile, M, N, lane);
         __syncthreads();
     }
 }
@@ -217,7 +130,7 @@ gemm_nt_mfma_kernel(const bf16* __restrict__ A, int64_t lda, const bf16* __restr
 bool gemm_nt_mfma_supported(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K,
                             int epilogue, const EpiParams& ep) {
     auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
-    if (K % BK || N % 16 || lda % 8 || ldb % 8 || ep.ldo % 8) return false;
+    if (K % 64 || N % 16 || lda % 8 || ldb % 8 || ep.ldo % 8) return false;
     if (!al16(A) || !al16(B) || !al16(ep.out)) return false;
     if (ep.bias && !al16(ep.bias)) return false;
     if (epilogue == VITED_EPI_GELU && !al16(ep.out2)) return false;
@@ -231,10 +144,17 @@ int gemm_nt_mfma(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t
                  const EpiParams& ep, hipStream_t s) {
     const int tiles_n = (int)ceil_div64(N, BN);
     const int ntiles = (int)(ceil_div64(M, BM) * tiles_n);
-    const size_t lds = 2 * STAGE_BYTES;
     const bf16* a = (const bf16*)A;
     const bf16* b = (const bf16*)B;
-#define LAUNCH_NT(E) hipLaunchKernelGGL((gemm_nt_mfma_kernel<E>), dim3(ntiles), dim3(256), lds, s, a, lda, b, ldb, M, N, K, tiles_n, ntiles, ep)
+    static const int force_bk = getenv("VITED_NT_BK") ? atoi(getenv("VITED_NT_BK")) : 0;  // tuning/diagnostic override
+    const bool shallow = force_bk ? force_bk == 32 : K <= 512;
+#define LAUNCH_NT(E)                                                                                                        \
+    do {                                                                                                                    \
+        if (shallow)                                                                                                        \
+            hipLaunchKernelGGL((gemm_nt_mfma_kernel<E, 32>), dim3(ntiles), dim3(256), 2 * NtCfg<32>::STAGE_BYTES, s, a, lda, b, ldb, M, N, K, tiles_n, ntiles, ep); \
+        else                                                                                                                \
+            hipLaunchKernelGGL((gemm_nt_mfma_kernel<E, 64>), dim3(ntiles), dim3(256), 2 * NtCfg<64>::STAGE_BYTES, s, a, lda, b, ldb, M, N, K, tiles_n, ntiles, ep); \
+    } while (0)
     switch (epilogue) {
         case VITED_EPI_STORE: LAUNCH_NT(VITED_EPI_STORE); break;
         case VITED_EPI_GELU: LAUNCH_NT(VITED_EPI_GELU); break;

@@ -1,0 +1,123 @@
+// Epilogue of the bf16 MFMA NT GEMM.  The 64 x 64 accumulator tile of a wave goes through a
+// per-wave LDS scratch 16 rows at a time and comes back in a store-friendly ownership:
+//   bf16 outputs : lane -> 2 x (row, 8 consecutive columns): 8 lanes x 16 B = one 128-byte row
+//                  segment, 8 rows per store instruction;
+//   fp32 outputs : lane -> 4 x (row, 4 consecutive columns): 16 lanes x 16 B = one 256-byte row
+//                  segment, 4 rows per store instruction.
+// Every global access of the epilogue (bias, residual, saved pre-activation, outputs) is therefore a
+// full-cache-line, 16-byte-per-lane access.  Operands that do not depend on the accumulators are
+// fetched into registers BEFORE the main loop (EpiPrefetch).
+#pragma once
+#include "gemm_epilogue.h"
+
+#define SCRATCH_LD 68  // floats per row of the per-wave epilogue scratch (16 rows)
+#define SCRATCH_BYTES (16 * SCRATCH_LD * 4)
+
+template <int EPI> struct EpiTraits {
+    static constexpr bool F32_OUT = (EPI == VITED_EPI_RESIDUAL || EPI == VITED_EPI_STORE_F32);
+    static constexpr int PIECES = F32_OUT ? 4 : 2;      // (row, vector) pieces per lane per 16-row sub-tile
+    static constexpr int WIDTH = F32_OUT ? 4 : 8;       // consecutive columns per piece
+    static constexpr int ROWS_PER_PIECE = 16 / PIECES;  // rows covered by one store instruction
+    __device__ static __forceinline__ int row(int lane, int piece) {
+        return F32_OUT ? piece * 4 + (lane >> 4) : piece * 8 + (lane >> 3);
+    }
+    __device__ static __forceinline__ int col(int lane) { return F32_OUT ? (lane & 15) * 4 : (lane & 7) * 8; }
+};
+
+template <int EPI> struct EpiPrefetch {
+    f32x4 res[EPI == VITED_EPI_RESIDUAL ? 4 : 1][4];          // [sub-tile][piece]
+    bf16x8 aux[EPI == VITED_EPI_MUL_GELU_GRAD ? 4 : 1][2];    // [sub-tile][piece]
+    f32x4 bias[2];                                            // this lane's 4 or 8 columns
+};
+
+__device__ __forceinline__ void remap_rows(const EpiParams& p, int64_t m, int64_t& orow, int64_t& rrow) {
+    orow = m;
+    rrow = m;
+    if (p.rows_per_batch > 0) {
+        const int64_t b = m / p.rows_per_batch, r = m - b * p.rows_per_batch + p.row_offset;
+        orow = b * p.out_rows_per_batch + r;
+        rrow = p.residual_bcast ? r : orow;
+    }
+}
+
+// mtile = first row of the wave's 64-row slab, ntile = first column of its 64-column slab
+template <int EPI>
+__device__ __forceinline__ void epilogue_prefetch(const EpiParams& p, EpiPrefetch<EPI>& pf, int64_t mtile, int64_t ntile, int64_t M,
+                                                  int64_t N, int lane) {
+    using T = EpiTraits<EPI>;
+    const int64_t n = ntile + T::col(lane);
+    const bool ncol = n < N;
+    pf.bias[0] = (p.bias && ncol) ? *(const f32x4*)(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+    pf.bias[1] = (p.bias && ncol && T::WIDTH == 8) ? *(const f32x4*)(p.bias + n + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (EPI == VITED_EPI_RESIDUAL) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int pc = 0; pc < 4; ++pc) {
+                const int64_t m = mtile + i * 16 + T::row(lane, pc);
+                int64_t orow, rrow;
+                remap_rows(p, m, orow, rrow);
+                pf.res[i][pc] = (m < M && ncol) ? *(const f32x4*)(p.residual + rrow * p.ldo + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+    }
+    if constexpr (EPI == VITED_EPI_MUL_GELU_GRAD) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int pc = 0; pc < 2; ++pc) {
+                const int64_t m = mtile + i * 16 + T::row(lane, pc);
+                pf.aux[i][pc] = (m < M && ncol) ? *(const bf16x8*)((const bf16*)p.aux + m * p.ldo + n)
+                                                : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            }
+    }
+}
+
+// one 16-row sub-tile i of the wave's slab: scratch (fp32 [16][SCRATCH_LD]) -> global
+template <int EPI>
+__device__ __forceinline__ void epilogue_subtile(const EpiParams& p, const EpiPrefetch<EPI>& pf, const float* sc, int i,
+                                                 int64_t mtile, int64_t ntile, int64_t M, int64_t N, int lane) {
+    using T = EpiTraits<EPI>;
+    const int64_t n = ntile + T::col(lane);
+    if (n >= N) return;
+#pragma unroll
+    for (int pc = 0; pc < T::PIECES; ++pc) {
+        const int r = T::row(lane, pc);
+        const int64_t m = mtile + i * 16 + r;
+        if (m >= M) continue;
+        const float* s = sc + r * SCRATCH_LD + T::col(lane);
+        if constexpr (T::F32_OUT) {
+            f32x4 v = *(const f32x4*)s;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += pf.bias[0][e];
+            int64_t orow = m, rrow = m;
+            if constexpr (EPI == VITED_EPI_RESIDUAL) {
+                remap_rows(p, m, orow, rrow);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += pf.res[i][pc][e];
+            }
+            *(f32x4*)((float*)p.out + orow * p.ldo + n) = v;
+        } else {
+            const f32x4 lo = *(const f32x4*)s, hi = *(const f32x4*)(s + 4);
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = lo[e] + pf.bias[0][e];
+                v[4 + e] = hi[e] + pf.bias[1][e];
+            }
+            if constexpr (EPI == VITED_EPI_MUL_GELU_GRAD) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_fast((float)pf.aux[i][pc][e]);
+            }
+            bf16x8 pk;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pk[e] = (bf16)v[e];
+            *(bf16x8*)((bf16*)p.out + m * p.ldo + n) = pk;
+            if constexpr (EPI == VITED_EPI_GELU) {
+                bf16x8 pg;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pg[e] = (bf16)gelu_fast(v[e]);
+                *(bf16x8*)((bf16*)p.out2 + m * p.ldo + n) = pg;
+            }
+        }
+    }
+}
