@@ -161,6 +161,27 @@ def main():
     opt = torch.optim.AdamW(groups, lr=lr, weight_decay=0.05, eps=1e-8, betas=(0.9, 0.999), fused=True, capturable=use_graph)
     step = engine.TrainStep(model, opt, clip_grad=5.0, amp=not args.fp32, use_graph=use_graph, compress_bf16=args.compress_bf16)
 
+    roof = None
+    if rank == 0 and not args.no_roofline:
+        step.step(x, y)                      # eager: sizes workspaces, builds weight shadows
+        with LaunchTimer(V.ops) as lt:       # same step, launched eagerly so each launch can be bracketed
+            for _ in range(2):
+                step.flat.zero()
+                step._fwd_bwd(x, y)
+            agg = lt.summary()
+        kernels = {k: {'launches': v['launches'], 'avg_us': round(1e3 * v['ms'] / v['launches'], 2),
+                       'total_ms_per_step': round(v['ms'] / 2, 3), 'tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 1)}
+                   for k, v in sorted(agg.items(), key=lambda kv: -kv[1]['ms'])}
+        dom = next(iter(kernels))
+        d = agg[dom]
+        achieved = d['flops'] / (d['ms'] * 1e-3) / 1e12
+        roof = {'roofline': {'bound': 'mfma', 'kernel': dom, 'achieved': round(achieved, 1), 'peak': PEAK_BF16_DENSE_TFLOPS,
+                             'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_BF16_DENSE_TFLOPS, 4), 'traffic': None,
+                             'avg_launch_us': round(1e3 * d['ms'] / d['launches'], 2), 'launches_per_step': d['launches'] // 2},
+                'kernels': kernels}
+        step.flat.zero()
+    if world > 1:
+        dist.barrier()
     # setup (eager steps + graph capture) and W warm-up steps, all untimed
     for _ in range(3 if use_graph else 1):
         step.step(x, y)
@@ -199,22 +220,8 @@ def main():
         'loss': round(loss_val, 5),
     }
 
-    if rank == 0 and not args.no_roofline:
-        with LaunchTimer(V.ops) as lt:       # same step, launched eagerly so each launch can be bracketed
-            for _ in range(2):
-                step.flat.zero()
-                step._fwd_bwd(x, y)
-            agg = lt.summary()
-        kernels = {k: {'launches': v['launches'], 'avg_us': round(1e3 * v['ms'] / v['launches'], 2),
-                       'total_ms_per_step': round(v['ms'] / 2, 3), 'tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 1)}
-                   for k, v in sorted(agg.items(), key=lambda kv: -kv[1]['ms'])}
-        dom = next(iter(kernels))
-        d = agg[dom]
-        achieved = d['flops'] / (d['ms'] * 1e-3) / 1e12
-        out['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': round(achieved, 1), 'peak': PEAK_BF16_DENSE_TFLOPS,
-                           'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_BF16_DENSE_TFLOPS, 4), 'traffic': None,
-                           'avg_launch_us': round(1e3 * d['ms'] / d['launches'], 2), 'launches_per_step': d['launches'] // 2}
-        out['kernels'] = kernels
+    if roof is not None:
+        out.update(roof)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import vited_oracle as vo
         pjs = cfg.MODEL.PJS

@@ -1,0 +1,93 @@
+"""CPU: the config surface and the model factory keep the reference's contract."""
+import argparse
+import os
+
+import pytest
+import torch
+
+from oracle import vited_oracle as vo
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CFG_A = os.path.join(ROOT, 'configs', 'puzzle', 'div2k_erosion7_4bin_patch8_64.yaml')
+CFG_H = os.path.join(ROOT, 'configs', 'hisfrag', 'hisfrag20_patch16_512.yaml')
+CFG_T = os.path.join(ROOT, 'configs', 'test', 'test_pjs_hisfrag20_patch32_64.yaml')
+
+
+def test_yaml_defaults_and_overrides(vited):
+    c = vited.config_from_yaml(CFG_A)
+    assert (c.MODEL.TYPE, c.MODEL.NUM_CLASSES, c.DATA.IMG_SIZE) == ('pjs', 4, 64)
+    assert (c.MODEL.PJS.EMBED_DIM, c.MODEL.PJS.PATCH_SIZE, c.MODEL.PJS.NUM_HEADS, c.MODEL.PJS.DEPTH, c.MODEL.PJS.C_DEPTH) == (384, 8, 12, 8, 8)
+    assert c.TRAIN.CLIP_GRAD == 5.0 and c.AMP_ENABLE is True and c.TRAIN.OPTIMIZER.BETAS == (0.9, 0.999)
+    assert c.OUTPUT == os.path.join('', 'div2k_erosion7_4bin_patch8_64', 'default')
+    h = vited.config_from_yaml(CFG_H)
+    assert (h.MODEL.PJS.NUM_HEADS, h.MODEL.PJS.DEPTH, h.MODEL.PJS.C_DEPTH, h.DATA.IMG_SIZE, h.MODEL.NUM_CLASSES) == (6, 12, 12, 512, 1)
+    with pytest.raises(AttributeError):
+        c.MODEL.NUM_CLASSES = 7           # frozen
+    o = vited.config_from_yaml(CFG_A, ['MODEL.PJS.DEPTH', '2', 'TRAIN.BASE_LR', '3e-4', 'DATA.BATCH_SIZE', '1024'])
+    assert o.MODEL.PJS.DEPTH == 2 and o.TRAIN.BASE_LR == 3e-4 and o.DATA.BATCH_SIZE == 1024
+    with pytest.raises(KeyError):
+        vited.config_from_yaml(CFG_A, ['MODEL.NOPE', '1'])
+    with pytest.raises(ValueError):
+        vited.config_from_yaml(CFG_A, ['MODEL.PJS.DEPTH', 'deep'])
+
+
+def test_cli_arguments_and_base_includes(vited, tmp_path):
+    child = tmp_path / 'child.yaml'
+    child.write_text(f'BASE: ["{CFG_A}"]\nMODEL:\n  NAME: child\n  PJS:\n    C_DEPTH: 3\n')
+    ns = argparse.Namespace(cfg=str(child), opts=['SEED', '7'], batch_size=32, output='out', tag='t1', disable_amp=True,
+                            accumulation_steps=2, resume='', pretrained=None)
+    c = vited.get_config(ns)
+    assert c.MODEL.PJS.EMBED_DIM == 384 and c.MODEL.PJS.C_DEPTH == 3 and c.MODEL.NAME == 'child'
+    assert c.DATA.BATCH_SIZE == 32 and c.DATA.TEST_BATCH_SIZE == 32 and c.AMP_ENABLE is False and c.SEED == 7
+    assert c.TRAIN.ACCUMULATION_STEPS == 2 and c.OUTPUT == os.path.join('out', 'child', 't1')
+    assert 'EMBED_DIM: 384' in c.dump()
+
+
+@pytest.mark.parametrize('cfg,params,flops', [(CFG_A, 33_236_356, 4_433_132_544), (CFG_H, 50_392_321, 160_764_807_936)])
+def test_build_model_matches_reference_layout(vited, cfg, params, flops):
+    m = vited.build_model(vited.config_from_yaml(cfg))
+    assert sum(p.numel() for p in m.parameters()) == params      # SURVEY section 8 counts
+    assert m.flops() == flops
+    pjs = vited.config_from_yaml(cfg).MODEL.PJS
+    s = vo.ViTEDShape(img_size=m.img_size, patch_size=m.patch_size, num_classes=m.num_classes, embed_dim=m.embed_dim,
+                      depth=m.depth, c_depth=m.c_depth, num_heads=m.num_heads)
+    ref = vo.state_dict_spec(s)
+    got = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert list(got.keys()) == list(ref.keys()) and got == dict(ref)
+    # optimizer grouping rule of misc/optimizer.py:36-46 sees the same names / ranks
+    groups = vited.engine.param_groups_no_decay_1d(m)
+    assert sum(p.numel() for p in groups[0]['params']) + sum(p.numel() for p in groups[1]['params']) == params
+    assert all(p.ndim >= 2 for p in groups[0]['params']) and groups[1]['weight_decay'] == 0.
+    assert pjs.QKV_BIAS is True
+
+
+def test_checkpoint_roundtrip_with_oracle_weights(vited):
+    s = vo.SHAPE_T
+    o = vo.fill_closed_form_(vo.OracleViTED(s))
+    m = vited.build_model(vited.config_from_yaml(CFG_T))
+    missing, unexpected = m.load_state_dict({'model': o.state_dict()}['model'], strict=False)   # misc/utils.py:27
+    assert not missing and not unexpected
+    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), o.state_dict().values()))
+    assert m.head.weight.shape == (1, 32) and m.head.bias.shape == (1,)                          # misc/utils.py:110-118
+
+
+def test_product_has_no_cpu_fallback(vited):
+    m = vited.build_model(vited.config_from_yaml(CFG_T))
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        m(torch.zeros(2, 2, 3, 64, 64))
+    with pytest.raises(AssertionError):
+        m.to('cpu')(torch.zeros(2, 3, 3, 64, 64))
+    with pytest.raises(NotImplementedError):
+        vited.VisionTransformerCustom(img_size=64, patch_size=8, embed_dim=384, keep_attn=True)
+    with pytest.raises(NotImplementedError):
+        cfg = vited.config_from_yaml(CFG_T, ['MODEL.TYPE', 'vit'])
+        vited.build_model(cfg)
+
+
+def test_product_never_imports_the_oracle():
+    """The product package must not route through oracle/ (it is test infrastructure)."""
+    pkg = os.path.join(ROOT, 'vit-ed_amd')
+    for fn in os.listdir(pkg):
+        if fn.endswith('.py'):
+            src = open(os.path.join(pkg, fn)).read()
+            assert 'import oracle' not in src and 'from oracle' not in src, fn

@@ -1,0 +1,107 @@
+"""CPU, 2 processes over gloo: the flat-gradient data-parallel plumbing (the RCCL path on the GPU
+box uses the same code with backend 'nccl').  The CPU oracle stands in for the model - the engine
+is model-agnostic."""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import vited_oracle as vo
+
+SHAPE = vo.ViTEDShape(img_size=32, patch_size=8, embed_dim=64, num_heads=2, depth=1, c_depth=1, num_classes=4)
+
+
+def _data(n):
+    g = torch.Generator().manual_seed(123)
+    x = torch.randn(n, 2, 3, 32, 32, generator=g).clamp(-1, 1)
+    y = (torch.rand(n, 4, generator=g) > 0.75).float()
+    return x, y
+
+
+def _worker(rank, world, port, compress, out):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import vited_amd
+    from vited_amd import engine
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    lr, r, w = engine.configure_ddp()
+    assert (r, w) == (rank, world) and dist.get_backend() == 'gloo'
+    torch.manual_seed(100 + rank)                       # different init per rank ...
+    model = vo.OracleViTED(SHAPE)
+    engine.broadcast_parameters(model)                  # ... until rank 0's parameters are broadcast (DDP ctor semantics)
+    opt = torch.optim.AdamW(engine.param_groups_no_decay_1d(model), lr=1e-3, weight_decay=0.05)
+    step = engine.TrainStep(model, opt, clip_grad=5.0, amp=False, compress_bf16=compress)
+    x, y = _data(8)
+    shard = slice(rank, None, world)                    # strided shards, data/samplers.py:50
+    step.flat.zero()
+    step._fwd_bwd(x[shard], y[shard])
+    step.flat.all_reduce_mean()
+    grads = step.flat.flat.clone()
+    loss = step.step(x[shard], y[shard])                # full step: every rank must end with identical parameters
+    params = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    gathered = [torch.empty_like(params) for _ in range(world)]
+    dist.all_gather(gathered, params)
+    if rank == 0:
+        torch.save({'grads': grads, 'same_params': all(torch.equal(g, gathered[0]) for g in gathered), 'loss': float(loss),
+                    'state': model.state_dict()}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('compress', [False, True])
+def test_two_rank_gradient_allreduce_equals_full_batch(tmp_path, compress):
+    out = str(tmp_path / 'r0.pt')
+    port = 29600 + (os.getpid() % 300) + (50 if compress else 0)
+    mp.spawn(_worker, args=(2, port, compress, out), nprocs=2, join=True)
+    res = torch.load(out, weights_only=True)
+    assert res['same_params']
+    # reference: one process, whole batch, same initial parameters (rank 0's, seed 100)
+    torch.manual_seed(100)
+    model = vo.OracleViTED(SHAPE)
+    x, y = _data(8)
+    torch.nn.functional.binary_cross_entropy_with_logits(model(x), y).backward()
+    full = torch.cat([p.grad.reshape(-1) for p in model.parameters() if p.requires_grad])
+    tol = dict(rtol=2e-2, atol=2e-3 * float(full.abs().max())) if compress else dict(rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(res['grads'], full, **tol)   # mean of shard gradients == full-batch gradient
+
+
+def test_flat_gradients_single_process_semantics():
+    import vited_amd
+    from vited_amd import engine
+    torch.manual_seed(0)
+    model = vo.OracleViTED(SHAPE)
+    flat = engine.FlatGradients(model.parameters())
+    assert flat.flat.numel() == sum(p.numel() for p in model.parameters())
+    x, y = _data(4)
+    torch.nn.functional.binary_cross_entropy_with_logits(model(x), y).backward()
+    ref = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+    assert torch.equal(ref, flat.flat) and all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(flat.params, flat.views))
+    torch.nn.functional.binary_cross_entropy_with_logits(model(x), y).backward()          # accumulation keeps the views
+    torch.testing.assert_close(flat.flat, 2 * ref)
+    norm = flat.clip_(0.5 * float(torch.linalg.vector_norm(flat.flat)))
+    torch.testing.assert_close(norm, torch.linalg.vector_norm(2 * ref))
+    torch.testing.assert_close(torch.linalg.vector_norm(flat.flat), 0.5 * norm, rtol=1e-4, atol=1e-6)
+    model.zero_grad(set_to_none=True)                     # the reference's optimizer.zero_grad() default
+    flat.zero()
+    assert all(p.grad is v for p, v in zip(flat.params, flat.views)) and float(flat.flat.abs().max()) == 0
+
+
+def test_scaler_call_shape_matches_reference():
+    """misc/engine.py:217-223 calls loss_scaler(loss, optimizer, clip_grad=..., parameters=..., update_grad=...)."""
+    import vited_amd
+    from vited_amd import engine
+    torch.manual_seed(0)
+    model = vo.OracleViTED(SHAPE)
+    opt = torch.optim.AdamW(engine.param_groups_no_decay_1d(model), lr=1e-3)
+    scaler = engine.NativeScalerWithGradNormCount()
+    x, y = _data(4)
+    before = model.head.weight.detach().clone()
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(model(x), y)
+    assert scaler(loss, opt, clip_grad=5.0, parameters=model.parameters(), update_grad=False) is None
+    assert torch.equal(before, model.head.weight)
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(model(x), y)
+    norm = scaler(loss, opt, clip_grad=5.0, parameters=model.parameters(), update_grad=True)
+    assert float(norm) > 0 and not torch.equal(before, model.head.weight) and scaler.state_dict()['scale'] == 1.0

@@ -157,6 +157,53 @@ def test_gemm_all_epilogues(vited, gpu, dtype, M, N, K):
     torch.testing.assert_close(dz.double(), _gemm_ref(a, w, None) * xg.grad, **tol)
 
 
+_AS_CHILD = """
+import math, sys, torch
+import torch.nn.functional as F
+sys.path.insert(0, {root!r})
+import vited_amd as vited
+ops, L = vited.ops, vited._lib
+gpu = torch.device('cuda:0')
+def _rand(shape, seed, scale=1.0, dtype=torch.float32):
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(gpu).to(dtype)
+tol = dict(rtol=1e-2, atol=1e-2)
+for M, N in {shapes!r}:
+    K = 384
+    a = _rand((M, K), 11, dtype=torch.bfloat16)
+    w = _rand((N, K), 12, 1 / math.sqrt(K), dtype=torch.bfloat16)
+    bias = _rand((N,), 13)
+    ref = a.double() @ w.double().t() + bias.double()
+    out = ops.gemm(a, w, bias=bias)
+    assert ops.last_paths()[0] == 3, ops.last_paths()
+    torch.testing.assert_close(out.double(), ref, **tol)
+    z, u = ops.gemm(a, w, epilogue=L.EPI_GELU, bias=bias)
+    torch.testing.assert_close(z.double(), ref, **tol)
+    torch.testing.assert_close(u.double(), F.gelu(ref), **tol)
+    o32 = ops.gemm(a, w, epilogue=L.EPI_STORE_F32)
+    torch.testing.assert_close(o32.double(), ref - bias.double(), rtol=2e-4, atol=2e-4)
+    assert torch.equal(out, ops.gemm(a, w, bias=bias))
+print('AS-OK')
+"""
+
+
+def test_gemm_persistent_activation_stationary(gpu):
+    """The opt-in persistent kernel for K = 384 Linears (gemm_nt_as.hip, VITED_NT=as): unit ranges that
+    start mid m-tile, span m-tile changes (A reload) and wrap the weight ring many times must all give
+    the right answer - every output element against fp64 on the same bf16-rounded operands.  The
+    kernel family is latched from the environment at the first GEMM of a process, so the checks run in
+    ONE child interpreter with VITED_NT=as (one extra GPU process, within the box's limit)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    shapes = [(256, 64), (768, 1536), (25600, 1152), (66560, 384), (16640, 768)]
+    code = _AS_CHILD.format(root=root, shapes=shapes)
+    r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, VITED_NT='as'), capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and 'AS-OK' in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_gemm_patch_embed_row_remap(vited, gpu, dtype):
     """RESIDUAL epilogue with the cls-row remap and the broadcast pos_embed table."""

@@ -5,7 +5,7 @@ The directory name is not a Python identifier; import it with
 root.  Public surface: ``build_model``, ``get_config`` / ``config_from_yaml``,
 ``VisionTransformerCustom`` and the ``ops`` (functional C-ABI wrappers).
 """
-from . import _lib, config, functions, ops  # noqa: F401
+from . import _lib, config, engine, functions, ops  # noqa: F401
 from .build import build_model  # noqa: F401
 from .config import config_from_yaml, get_config  # noqa: F401
 from .model import VisionTransformerCustom  # noqa: F401

@@ -10,7 +10,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libvited_hip.so')
+LIB_PATH = os.environ.get('VITED_LIB') or os.path.join(_HERE, 'libvited_hip.so')  # VITED_LIB: kernel-experiment builds
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'vited.h')
 
 F32, BF16 = 0, 1

@@ -1,5 +1,8 @@
 // C-ABI GEMM entry points: argument validation and dispatch between the bf16 MFMA kernels and the
 // portable fp32-FMA kernels.
+#include <stdlib.h>
+#include <string.h>
+
 #include "gemm_kernels.h"
 
 static thread_local int g_last_gemm_path = 0;
@@ -29,6 +32,15 @@ extern "C" int vited_gemm(const void* A, int64_t lda, const void* B, int64_t ldb
     ep.row_offset = row_offset;
     ep.residual_bcast = residual_bcast;
     hipStream_t s = (hipStream_t)stream;
+    // VITED_NT=as opts the K = 384 Linears into the persistent activation-stationary kernel
+    // (gemm_nt_as.hip).  Measured on MI355X it ties the tile kernel (DESIGN.md section "GEMM"), so the
+    // tile kernel stays the default; the persistent one is kept as the base of the fused-block work.
+    static const char* nt_env = getenv("VITED_NT");
+    static const bool use_as = nt_env && !strcmp(nt_env, "as");
+    if (dtype == VITED_BF16 && b_layout == VITED_B_NK && use_as && gemm_nt_as_supported(A, lda, B, ldb, M, N, K, epilogue, ep)) {
+        g_last_gemm_path = 3;
+        return gemm_nt_as(A, lda, B, ldb, M, N, K, epilogue, ep, s);
+    }
     if (dtype == VITED_BF16 && b_layout == VITED_B_NK && gemm_nt_mfma_supported(A, lda, B, ldb, M, N, K, epilogue, ep)) {
         g_last_gemm_path = 2;
         return gemm_nt_mfma(A, lda, B, ldb, M, N, K, epilogue, ep, s);

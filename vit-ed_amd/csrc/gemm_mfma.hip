@@ -108,10 +108,22 @@ gemm_nt_mfma_kernel(const bf16* __restrict__ A, int64_t lda, const bf16* __restr
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < 4; ++j) {
+#ifdef NT_DBG_NO_MFMA
+                    asm volatile("" ::"v"(af[i]), "v"(bf_[j]));
+#else
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf_[j], acc[i][j], 0, 0, 0);
+#endif
+                }
         }
     }
+#ifdef NT_DBG_NO_EPI
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
+    return;
+#endif
     // ---- epilogue: accumulators -> per-wave LDS scratch -> full-line row segments (gemm_nt_epilogue.h)
     __syncthreads();
     float* sc = (float*)(smem + wave * SCRATCH_BYTES);
