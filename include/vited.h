@@ -54,7 +54,8 @@ int vited_abi_version(void);
 const char* vited_strerror(int code);
 
 /* Which implementation the last vited_gemm / vited_attention_* call on this thread dispatched to:
- * 0 = none yet, 1 = portable fp32-FMA kernel, 2 = bf16 MFMA kernel.  Test/diagnostic use. */
+ * 0 = none yet, 1 = portable fp32-FMA kernel, 2 = bf16 MFMA kernel, 3 = persistent bf16 MFMA GEMM
+ * (opt-in, VITED_NT=as).  Test/diagnostic use. */
 int vited_last_gemm_path(void);
 int vited_last_attention_path(void);
 

@@ -224,11 +224,18 @@ gemm_tn_mfma_kernel(const bf16* __restrict__ dY, int64_t lddy, const bf16* __res
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = wave >> 1, wc = wave & 1;
-    const int64_t n0 = (int64_t)(blockIdx.x / tiles_k) * 128, kc0 = (int64_t)(blockIdx.x % tiles_k) * 128;
-    const int64_t mb = (int64_t)blockIdx.y * rows_per_split;
+    // All tiles of one M-split read the same dY / X rows: keep them on ONE XCD (its L2 then serves the
+    // re-reads) by giving each XCD a contiguous run of the (split-major, tile-minor) order.
+    const int ntile = gridDim.x;
+    const int lin = xcd_remap(blockIdx.x + blockIdx.y * ntile, ntile * gridDim.y);
+    const int split = lin / ntile, tile_id = lin - split * ntile;
+    const int64_t n0 = (int64_t)(tile_id / tiles_k) * 128, kc0 = (int64_t)(tile_id % tiles_k) * 128;
+    const int64_t mb = (int64_t)split * rows_per_split;
     int64_t me = mb + rows_per_split;
     me = me < M ? me : M;
-    const bool do_bias = BIAS && kc0 == 0 && wc == 0;  // wave-uniform
+    // bias rows are dealt round-robin over the (k-tile, wave-column) pairs that share an n-range, so no
+    // workgroup carries the whole extra MFMA load (a straggler would set the kernel time)
+    const int bias_pair = (tile_id % tiles_k) * 2 + wc, bias_pairs = tiles_k * 2;   // wave-uniform
 
     f32x4 acc[4][4], accb[4];
 #pragma unroll
@@ -287,13 +294,14 @@ gemm_tn_mfma_kernel(const bf16* __restrict__ dY, int64_t lddy, const bf16* __res
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf_[j], acc[i][j], 0, 0, 0);
-            if (do_bias) {
+            if constexpr (BIAS) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, accb[i], 0, 0, 0);
+                for (int i = 0; i < 4; ++i)
+                    if (i % bias_pairs == bias_pair) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, accb[i], 0, 0, 0);
             }
         }
     }
-    float* o = out + (int64_t)blockIdx.y * N * K;
+    float* o = out + (int64_t)split * N * K;
     const int fr = lane & 15, fq = lane >> 4;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -307,14 +315,16 @@ gemm_tn_mfma_kernel(const bf16* __restrict__ dY, int64_t lddy, const bf16* __res
             }
         }
     }
-    if (do_bias && fr == 0) {
-        float* bo = bias_out + (int64_t)blockIdx.y * N;
+    if (BIAS && fr == 0) {
+        float* bo = bias_out + (int64_t)split * N;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
+            if (i % bias_pairs == bias_pair) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int64_t n = n0 + wr * 64 + i * 16 + fq * 4 + e;
-                if (n < N) bo[n] = accb[i][e];
+                for (int e = 0; e < 4; ++e) {
+                    const int64_t n = n0 + wr * 64 + i * 16 + fq * 4 + e;
+                    if (n < N) bo[n] = accb[i][e];
+                }
             }
     }
 }
