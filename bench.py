@@ -137,10 +137,14 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py measures the MI355X HIP path; no GPU is visible (the CPU oracle is only the baseline leg)')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    # rehearsal knobs (a 1-GPU box cannot run 2 RCCL ranks): VITED_DIST_BACKEND=gloo VITED_FORCE_DEVICE=0
+    dev_index = int(os.environ.get('VITED_FORCE_DEVICE', local_rank))
+    backend = os.environ.get('VITED_DIST_BACKEND', 'nccl')
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
     if world > 1:
-        dist.init_process_group('nccl', init_method='env://', world_size=world, rank=rank, device_id=dev)
+        kw = {'device_id': dev} if backend == 'nccl' else {}
+        dist.init_process_group(backend, init_method='env://', world_size=world, rank=rank, **kw)
     import vited_amd as V
     from vited_amd import engine
     V._lib.load()
@@ -163,7 +167,8 @@ def main():
 
     roof = None
     if rank == 0 and not args.no_roofline:
-        step.step(x, y)                      # eager: sizes workspaces, builds weight shadows
+        step.flat.zero()
+        step._fwd_bwd(x, y)                  # eager warm-up: sizes workspaces, builds weight shadows (no collective, no update)
         with LaunchTimer(V.ops) as lt:       # same step, launched eagerly so each launch can be bracketed
             for _ in range(2):
                 step.flat.zero()

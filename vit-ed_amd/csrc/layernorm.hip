@@ -217,26 +217,29 @@ layernorm_bwd_kernel(const T* __restrict__ dy, int64_t dy_ld, const float* __res
     }
 }
 
-// out[c] = sum_p partial[p][c]; block = 64 columns x 4 partial-row groups, LDS combine
+// out[c] = sum_p partial[p][c]; block = 16 columns x 16 partial-row groups (a coalesced 64-byte read per
+// group and step), LDS combine: 4x more workgroups and 4x shorter loops than a 64-column block
 __global__ void __launch_bounds__(256)
 ln_bwd_finish_kernel(const float* __restrict__ partial, int nparts, int width, float* __restrict__ dgamma,
                      float* __restrict__ dbeta, int dim) {
-    __shared__ float red[4][64];
-    const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cx;
+    __shared__ float red[16][17];
+    const int cx = threadIdx.x & 15, py = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cx;
     float a0 = 0.f, a1 = 0.f;
     if (c < width) {
         int p = py;
-        for (; p + 4 < nparts; p += 8) {
+        for (; p + 16 < nparts; p += 32) {
             a0 += partial[(size_t)p * width + c];
-            a1 += partial[(size_t)(p + 4) * width + c];
+            a1 += partial[(size_t)(p + 16) * width + c];
         }
         if (p < nparts) a0 += partial[(size_t)p * width + c];
     }
     red[py][cx] = a0 + a1;
     __syncthreads();
     if (py == 0 && c < width) {
-        const float v = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v += red[k][cx];
         if (c < dim) dgamma[c] = v; else dbeta[c - dim] = v;
     }
 }
@@ -272,7 +275,7 @@ static int ln_bwd_launch(const void* dy, int64_t dy_ld, const float* x, int64_t 
         default: L(8); break;
     }
 #undef L
-    hipLaunchKernelGGL(ln_bwd_finish_kernel, dim3((2 * dim + 63) / 64), dim3(256), 0, s, ws, (int)blocks, 2 * dim, dgamma, dbeta, dim);
+    hipLaunchKernelGGL(ln_bwd_finish_kernel, dim3((2 * dim + 15) / 16), dim3(256), 0, s, ws, (int)blocks, 2 * dim, dgamma, dbeta, dim);
     return vited_check_launch();
 }
 
