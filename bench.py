@@ -28,7 +28,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_DENSE_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PF dense bf16 (never the 2:1-sparse figure)
-FLOPS_FWD_BWD_PER_PAIR_A = 13_299_397_632  # BASELINE.md section 2 (3 x 4,433,132,544)
 
 
 def parse():
@@ -155,6 +154,7 @@ def main():
         torch.manual_seed(cfg.SEED + rank)          # misc/engine.py:28
         model = V.build_model(cfg).to(dev)
     model.compute_dtype = torch.float32 if args.fp32 else torch.bfloat16
+    flops_per_pair = 3 * model.flops()          # fwd+bwd = 3 x fwd (13,299,397,632 at config A)
     engine.broadcast_parameters(model)
     B, S, C = args.batch, cfg.DATA.IMG_SIZE, cfg.MODEL.NUM_CLASSES
     x = torch.randn(B, 2, 3, S, S, device=dev).clamp_(-1, 1)
@@ -217,11 +217,11 @@ def main():
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32' if args.fp32 else 'bf16', 'data': 'synthetic',
-        'config': {'workload': f'{os.path.basename(args.cfg)} batch {B}/GPU, 64x64 random patch pairs, full train step '
+        'config': {'workload': f'{os.path.basename(args.cfg)} batch {B}/GPU, {S}x{S} random patch pairs, full train step '
                                f'(fwd+bwd+{"RCCL all-reduce+" if world > 1 else ""}clip+AdamW)',
                    'global_batch': B * world, 'parallelism': f'dp{world}', 'hipgraph': use_graph},
-        'step_tflops': round(pairs_per_s * FLOPS_FWD_BWD_PER_PAIR_A / 1e12, 2),
-        'step_frac_of_bf16_peak': round(pairs_per_s * FLOPS_FWD_BWD_PER_PAIR_A / 1e12 / (PEAK_BF16_DENSE_TFLOPS * world), 4),
+        'step_tflops': round(pairs_per_s * flops_per_pair / 1e12, 2),
+        'step_frac_of_bf16_peak': round(pairs_per_s * flops_per_pair / 1e12 / (PEAK_BF16_DENSE_TFLOPS * world), 4),
         'loss': round(loss_val, 5),
     }
 

@@ -249,7 +249,8 @@ def _sdpa_ref(q, k, v, heads, scale):
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('B,H,Nq,Nk,hd', [(3, 12, 64, 64, 32), (3, 12, 65, 65, 32), (2, 12, 65, 64, 32), (2, 6, 257, 256, 64),
-                                          (1, 6, 1025, 1024, 64), (2, 1, 5, 4, 32), (1, 2, 1, 1, 64)])
+                                          (1, 6, 1025, 1024, 64), (2, 1, 5, 4, 32), (1, 2, 1, 1, 64), (2, 3, 200, 130, 32),
+                                          (1, 6, 1024, 1024, 64), (1, 6, 1025, 1025, 64), (2, 2, 65, 65, 64), (1, 4, 129, 81, 32)])
 def test_attention_fwd_bwd(vited, gpu, dtype, B, H, Nq, Nk, hd):
     ops = vited.ops
     D = H * hd
@@ -263,8 +264,8 @@ def test_attention_fwd_bwd(vited, gpu, dtype, B, H, Nq, Nk, hd):
         kv = _rand((B, Nk, 2 * D), gpu, 2, dtype=dtype)
         k, v = kv[:, :, :D], kv[:, :, D:]
     o, lse = ops.attention_fwd(q, k, v, H, scale)
-    small = dtype == torch.bfloat16 and Nk <= 80 and Nq <= 80
-    assert ops.last_paths()[1] == (2 if small else 1)          # bf16 short sequences run the MFMA kernel
+    mfma = dtype == torch.bfloat16                              # bf16: short-sequence or tiled (flash) MFMA kernels
+    assert ops.last_paths()[1] == (2 if mfma else 1)
     qr, kr, vr = (t.double().clone().requires_grad_() for t in (q, k, v))
     o_ref, lse_ref = _sdpa_ref(qr, kr, vr, H, scale)
     tol = dict(rtol=1e-4, atol=1e-5) if dtype == torch.float32 else BF16_OUT
@@ -280,7 +281,7 @@ def test_attention_fwd_bwd(vited, gpu, dtype, B, H, Nq, Nk, hd):
         dk, dv = dkv[:, :, :D], dkv[:, :, D:]
     # the kernels consume the SAVED (storage-dtype) output o, like the reference's SDPA backward
     ops.attention_bwd(q, k, v, o, do, lse, H, scale, dq, dk, dv)
-    assert ops.last_paths()[1] == (2 if (small and hd == 32) else 1)
+    assert ops.last_paths()[1] == (2 if mfma else 1)
     btol = dict(rtol=2e-4, atol=2e-5) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2)
     torch.testing.assert_close(dq.double(), qr.grad, **btol)
     torch.testing.assert_close(dk.double(), kr.grad, **btol)

@@ -1,0 +1,435 @@
+// bf16 MFMA attention for long sequences (BASELINE config H: 1024 / 1025 tokens, head_dim 64):
+// tiled, online-softmax ("flash") forward and a two-kernel backward, no N x N tensor anywhere.
+//
+// Same register algebra as the short-sequence kernels (attention_mfma.hip): scores are computed
+// transposed (keys on accumulator rows, the query on the lane) so the softmax of a query lives in one
+// lane's registers plus two shuffles, and the probabilities ARE the next MFMA's operand.
+//
+//   forward   one workgroup = 4 waves x 32 queries of one (batch, head); 64-key K/V tiles are staged
+//             cooperatively (coalesced 16-byte loads -> registers -> XOR-swizzled LDS image, double
+//             buffered: the next tile's loads are in flight under the current tile's MFMAs); running
+//             max / sum per query, O rescaled per tile; LSE saved.
+//   backward  dQ kernel : the forward loop with S^T, dP^T = V dO^T, dS^T = P^T o (dP^T - delta),
+//                         dQ^T += K^T dS^T (K read transposed from the same LDS image); also writes
+//                         delta = rowsum(dO o O) for the second kernel.
+//             dKV kernel: one workgroup = 4 waves x 32 keys; loops over 64-query tiles of Q / dO / lse /
+//                         delta; S = Q K^T and dP = dO V^T put the query on accumulator rows, so
+//                         dV^T += dO^T P and dK^T += Q^T dS contract over accumulator rows again.
+//             Both kernels accumulate in registers across the loop: no atomics, bit-reproducible.
+#include "attention_tiles.h"
+
+#define FL_TILE 64   // keys (or queries) per LDS tile
+#define FL_W 2       // 16-row tiles per wave
+
+template <int HD> struct FlashCfg {
+    using C = SmallCfg<HD>;
+    static constexpr int TILE_BYTES = FL_TILE * C::ROW_BYTES;
+    static constexpr int CHUNKS_PER_ROW = HD / 8;
+    static constexpr int PASSES = FL_TILE * CHUNKS_PER_ROW / 256;   // 16-byte chunks per thread and tile
+};
+
+// cooperative tile copy, global -> registers (rows clamped to n-1) ...
+template <int HD>
+__device__ __forceinline__ void tile_to_regs(const bf16* base, int64_t ts, int row0, int n, int tid, bf16x8 (&r)[FlashCfg<HD>::PASSES]) {
+#pragma unroll
+    for (int c = 0; c < FlashCfg<HD>::PASSES; ++c) {
+        const int idx = tid + 256 * c;
+        const int row = idx / FlashCfg<HD>::CHUNKS_PER_ROW, ch = idx % FlashCfg<HD>::CHUNKS_PER_ROW;
+        int rr = row0 + row;
+        rr = rr < n ? rr : n - 1;
+        r[c] = *(const bf16x8*)(base + (int64_t)rr * ts + ch * 8);
+    }
+}
+// ... and registers -> LDS image (rows >= n zeroed)
+template <int HD>
+__device__ __forceinline__ void regs_to_tile(char* lds, int row0, int n, int tid, const bf16x8 (&r)[FlashCfg<HD>::PASSES]) {
+#pragma unroll
+    for (int c = 0; c < FlashCfg<HD>::PASSES; ++c) {
+        const int idx = tid + 256 * c;
+        const int row = idx / FlashCfg<HD>::CHUNKS_PER_ROW, ch = idx % FlashCfg<HD>::CHUNKS_PER_ROW;
+        bf16x8 v = r[c];
+        if (row0 + row >= n) v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        *(bf16x8*)(lds + SmallCfg<HD>::off(row, ch * 16)) = v;
+    }
+}
+// MFMA row fragment (row fr of 16-row tile t, k chunk g + 4c) out of an LDS image
+template <int HD>
+__device__ __forceinline__ void lds_row_frags(const char* lds, int t, int fr, int g, bf16x8 (&f)[HD / 32]) {
+#pragma unroll
+    for (int c = 0; c < HD / 32; ++c) f[c] = *(const bf16x8*)(lds + SmallCfg<HD>::off(16 * t + fr, 16 * (g + 4 * c)));
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+template <int HD>
+__global__ void __launch_bounds__(256)
+attn_fwd_flash_kernel(AttnArgs a) {
+    using C = SmallCfg<HD>;
+    using F = FlashCfg<HD>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][K tile | V tile]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, g = lane >> 4, qq = fr >> 2, p = fr & 3;
+    const int64_t b = blockIdx.z;
+    const int h = blockIdx.y;
+    const int nq = (int)a.nq, nk = (int)a.nk;
+    const int q0 = blockIdx.x * (64 * FL_W) + wave * (16 * FL_W);
+    const int64_t hoff = (int64_t)h * HD;
+    const bf16* qb = (const bf16*)a.q + b * a.q_bs + hoff;
+    const bf16* kb = (const bf16*)a.k + b * a.k_bs + hoff;
+    const bf16* vb = (const bf16*)a.v + b * a.v_bs + hoff;
+    const float sc = a.scale * LOG2E;
+
+    bf16x8 qf[FL_W][C::KCH];
+    f32x4 o[FL_W][C::DT];
+    float m[FL_W], l[FL_W];
+#pragma unroll
+    for (int w = 0; w < FL_W; ++w) {
+        load_row_frags<HD>(qb, a.q_ts, q0 + 16 * w, nq, fr, g, qf[w]);
+        m[w] = -INFINITY;
+        l[w] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt) o[w][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int ntiles = (nk + FL_TILE - 1) / FL_TILE;
+    bf16x8 kr[F::PASSES], vr[F::PASSES];
+    tile_to_regs<HD>(kb, a.k_ts, 0, nk, tid, kr);
+    tile_to_regs<HD>(vb, a.v_ts, 0, nk, tid, vr);
+    regs_to_tile<HD>(smem, 0, nk, tid, kr);
+    regs_to_tile<HD>(smem + F::TILE_BYTES, 0, nk, tid, vr);
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const char* ks = smem + (t & 1) * 2 * F::TILE_BYTES;
+        const char* vs = ks + F::TILE_BYTES;
+        if (t + 1 < ntiles) {   // next tile: loads fly under this tile's MFMAs
+            tile_to_regs<HD>(kb, a.k_ts, (t + 1) * FL_TILE, nk, tid, kr);
+            tile_to_regs<HD>(vb, a.v_ts, (t + 1) * FL_TILE, nk, tid, vr);
+        }
+        bf16x8 kf[4][C::KCH];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) lds_row_frags<HD>(ks, kt, fr, g, kf[kt]);
+#pragma unroll
+        for (int w = 0; w < FL_W; ++w) {
+            f32x4 st[4];
+            float tmax = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int c = 0; c < C::KCH; ++c) s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt][c], qf[w][c], s, 0, 0, 0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    s[e] = (t * FL_TILE + 16 * kt + 4 * g + e) < nk ? s[e] * sc : -INFINITY;
+                    tmax = fmaxf(tmax, s[e]);
+                }
+                st[kt] = s;
+            }
+            tmax = group_max4(tmax);
+            const float mn = fmaxf(m[w], tmax);
+            const float alpha = exp2f(m[w] - mn);
+            float ls = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float pe = exp2f(st[kt][e] - mn);
+                    st[kt][e] = pe;
+                    ls += pe;
+                }
+            l[w] = l[w] * alpha + group_sum4(ls);
+            m[w] = mn;
+#pragma unroll
+            for (int dt = 0; dt < C::DT; ++dt) {
+                f32x4 acc = o[w][dt];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] *= alpha;
+#pragma unroll
+                for (int k2 = 0; k2 < 2; ++k2)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<HD>(vs, k2, dt, g, qq, p), pack_pair(st[2 * k2], st[2 * k2 + 1]), acc, 0, 0, 0);
+                o[w][dt] = acc;
+            }
+        }
+        if (t + 1 < ntiles) {
+            char* nks = smem + ((t + 1) & 1) * 2 * F::TILE_BYTES;
+            regs_to_tile<HD>(nks, (t + 1) * FL_TILE, nk, tid, kr);
+            regs_to_tile<HD>(nks + F::TILE_BYTES, (t + 1) * FL_TILE, nk, tid, vr);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int w = 0; w < FL_W; ++w) {
+        const int q = q0 + 16 * w + fr;
+        if (q < nq) {
+            const float inv = 1.f / l[w];
+#pragma unroll
+            for (int dt = 0; dt < C::DT; ++dt) {
+                const bf16x4 ov = {(bf16)(o[w][dt][0] * inv), (bf16)(o[w][dt][1] * inv), (bf16)(o[w][dt][2] * inv), (bf16)(o[w][dt][3] * inv)};
+                *(bf16x4*)((bf16*)a.o + b * a.o_bs + (int64_t)q * a.o_ts + hoff + dt * 16 + 4 * g) = ov;
+            }
+            if (g == 0) a.lse[(b * a.heads + h) * a.nq + q] = (m[w] + log2f(l[w])) * LN2;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward 1/2: dQ (and delta)
+// ------------------------------------------------------------------------------------------------
+template <int HD>
+__global__ void __launch_bounds__(256)
+attn_bwd_dq_flash_kernel(AttnArgs a) {
+    using C = SmallCfg<HD>;
+    using F = FlashCfg<HD>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, g = lane >> 4, qq = fr >> 2, p = fr & 3;
+    const int64_t b = blockIdx.z;
+    const int h = blockIdx.y;
+    const int nq = (int)a.nq, nk = (int)a.nk;
+    const int q0 = blockIdx.x * (64 * FL_W) + wave * (16 * FL_W);
+    const int64_t hoff = (int64_t)h * HD;
+    const bf16* qb = (const bf16*)a.q + b * a.q_bs + hoff;
+    const bf16* kb = (const bf16*)a.k + b * a.k_bs + hoff;
+    const bf16* vb = (const bf16*)a.v + b * a.v_bs + hoff;
+    const bf16* ob = (const bf16*)a.o + b * a.o_bs + hoff;
+    const bf16* dob = (const bf16*)a.d_o + b * a.o_bs + hoff;
+    const float sc = a.scale * LOG2E;
+
+    bf16x8 qf[FL_W][C::KCH], dof[FL_W][C::KCH];
+    f32x4 dq[FL_W][C::DT];
+    float lse2[FL_W], dl[FL_W];
+#pragma unroll
+    for (int w = 0; w < FL_W; ++w) {
+        load_row_frags<HD>(qb, a.q_ts, q0 + 16 * w, nq, fr, g, qf[w]);
+        load_row_frags<HD>(dob, a.o_ts, q0 + 16 * w, nq, fr, g, dof[w]);
+        bf16x8 of[C::KCH];
+        load_row_frags<HD>(ob, a.o_ts, q0 + 16 * w, nq, fr, g, of);
+        float d = 0.f;
+#pragma unroll
+        for (int c = 0; c < C::KCH; ++c)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) d = fmaf((float)of[c][e], (float)dof[w][c][e], d);
+        dl[w] = group_sum4(d);
+        const int q = q0 + 16 * w + fr;
+        const int qc = q < nq ? q : nq - 1;
+        lse2[w] = a.lse[(b * a.heads + h) * a.nq + qc] * LOG2E;
+        if (g == 0 && q < nq) a.delta[(b * a.heads + h) * a.nq + q] = dl[w];
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt) dq[w][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int ntiles = (nk + FL_TILE - 1) / FL_TILE;
+    bf16x8 kr[F::PASSES], vr[F::PASSES];
+    tile_to_regs<HD>(kb, a.k_ts, 0, nk, tid, kr);
+    tile_to_regs<HD>(vb, a.v_ts, 0, nk, tid, vr);
+    regs_to_tile<HD>(smem, 0, nk, tid, kr);
+    regs_to_tile<HD>(smem + F::TILE_BYTES, 0, nk, tid, vr);
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const char* ks = smem + (t & 1) * 2 * F::TILE_BYTES;
+        const char* vs = ks + F::TILE_BYTES;
+        if (t + 1 < ntiles) {
+            tile_to_regs<HD>(kb, a.k_ts, (t + 1) * FL_TILE, nk, tid, kr);
+            tile_to_regs<HD>(vb, a.v_ts, (t + 1) * FL_TILE, nk, tid, vr);
+        }
+        bf16x8 kf[4][C::KCH], vf[4][C::KCH];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            lds_row_frags<HD>(ks, kt, fr, g, kf[kt]);
+            lds_row_frags<HD>(vs, kt, fr, g, vf[kt]);
+        }
+#pragma unroll
+        for (int w = 0; w < FL_W; ++w) {
+            f32x4 ds[4];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int c = 0; c < C::KCH; ++c) {
+                    s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt][c], qf[w][c], s, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[kt][c], dof[w][c], dp, 0, 0, 0);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float pe = (t * FL_TILE + 16 * kt + 4 * g + e) < nk ? exp2f(s[e] * sc - lse2[w]) : 0.f;
+                    ds[kt][e] = pe * (dp[e] - dl[w]);
+                }
+            }
+#pragma unroll
+            for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+                for (int k2 = 0; k2 < 2; ++k2)
+                    dq[w][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<HD>(ks, k2, dt, g, qq, p), pack_pair(ds[2 * k2], ds[2 * k2 + 1]), dq[w][dt], 0, 0, 0);
+        }
+        if (t + 1 < ntiles) {
+            char* nks = smem + ((t + 1) & 1) * 2 * F::TILE_BYTES;
+            regs_to_tile<HD>(nks, (t + 1) * FL_TILE, nk, tid, kr);
+            regs_to_tile<HD>(nks + F::TILE_BYTES, (t + 1) * FL_TILE, nk, tid, vr);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int w = 0; w < FL_W; ++w) {
+        const int q = q0 + 16 * w + fr;
+        if (q < nq) {
+#pragma unroll
+            for (int dt = 0; dt < C::DT; ++dt) {
+                const bf16x4 ov = {(bf16)(dq[w][dt][0] * a.scale), (bf16)(dq[w][dt][1] * a.scale), (bf16)(dq[w][dt][2] * a.scale), (bf16)(dq[w][dt][3] * a.scale)};
+                *(bf16x4*)((bf16*)a.dq + b * a.dq_bs + (int64_t)q * a.dq_ts + hoff + dt * 16 + 4 * g) = ov;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward 2/2: dK, dV
+// ------------------------------------------------------------------------------------------------
+template <int HD>
+__global__ void __launch_bounds__(256)
+attn_bwd_dkv_flash_kernel(AttnArgs a) {
+    using C = SmallCfg<HD>;
+    using F = FlashCfg<HD>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][Q tile | dO tile | lse 64 f32 | delta 64 f32]
+    constexpr int STAGE_BYTES = 2 * F::TILE_BYTES + 2 * FL_TILE * 4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, g = lane >> 4, qq = fr >> 2, p = fr & 3;
+    const int64_t b = blockIdx.z;
+    const int h = blockIdx.y;
+    const int nq = (int)a.nq, nk = (int)a.nk;
+    const int k0 = blockIdx.x * (64 * FL_W) + wave * (16 * FL_W);
+    const int64_t hoff = (int64_t)h * HD;
+    const bf16* qb = (const bf16*)a.q + b * a.q_bs + hoff;
+    const bf16* kb = (const bf16*)a.k + b * a.k_bs + hoff;
+    const bf16* vb = (const bf16*)a.v + b * a.v_bs + hoff;
+    const bf16* dob = (const bf16*)a.d_o + b * a.o_bs + hoff;
+    const float* lse_g = a.lse + (b * a.heads + h) * a.nq;
+    const float* del_g = a.delta + (b * a.heads + h) * a.nq;
+    const float sc = a.scale * LOG2E;
+
+    bf16x8 kf[FL_W][C::KCH], vf[FL_W][C::KCH];
+    f32x4 dk[FL_W][C::DT], dv[FL_W][C::DT];
+#pragma unroll
+    for (int w = 0; w < FL_W; ++w) {
+        load_row_frags<HD>(kb, a.k_ts, k0 + 16 * w, nk, fr, g, kf[w]);
+        load_row_frags<HD>(vb, a.v_ts, k0 + 16 * w, nk, fr, g, vf[w]);
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt) {
+            dk[w][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            dv[w][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    const int ntiles = (nq + FL_TILE - 1) / FL_TILE;
+    bf16x8 qr[F::PASSES], dor[F::PASSES];
+    float statr = 0.f;
+    auto load_stats = [&](int t) {
+        if (tid < 2 * FL_TILE) {
+            int q = t * FL_TILE + (tid & (FL_TILE - 1));
+            q = q < nq ? q : nq - 1;
+            statr = tid < FL_TILE ? lse_g[q] * LOG2E : del_g[q];
+        }
+    };
+    auto store_stats = [&](char* stage) {
+        if (tid < 2 * FL_TILE) ((float*)(stage + 2 * F::TILE_BYTES))[tid] = statr;
+    };
+    tile_to_regs<HD>(qb, a.q_ts, 0, nq, tid, qr);
+    tile_to_regs<HD>(dob, a.o_ts, 0, nq, tid, dor);
+    load_stats(0);
+    regs_to_tile<HD>(smem, 0, nq, tid, qr);
+    regs_to_tile<HD>(smem + F::TILE_BYTES, 0, nq, tid, dor);
+    store_stats(smem);
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const char* qs = smem + (t & 1) * STAGE_BYTES;
+        const char* dos = qs + F::TILE_BYTES;
+        const float* lse_s = (const float*)(qs + 2 * F::TILE_BYTES);
+        const float* del_s = lse_s + FL_TILE;
+        if (t + 1 < ntiles) {
+            tile_to_regs<HD>(qb, a.q_ts, (t + 1) * FL_TILE, nq, tid, qr);
+            tile_to_regs<HD>(dob, a.o_ts, (t + 1) * FL_TILE, nq, tid, dor);
+            load_stats(t + 1);
+        }
+#pragma unroll
+        for (int w = 0; w < FL_W; ++w) {
+            f32x4 pr[4], ds[4];
+#pragma unroll
+            for (int qt = 0; qt < 4; ++qt) {
+                bf16x8 qfr[C::KCH], dofr[C::KCH];
+                lds_row_frags<HD>(qs, qt, fr, g, qfr);
+                lds_row_frags<HD>(dos, qt, fr, g, dofr);
+                f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int c = 0; c < C::KCH; ++c) {
+                    s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr[c], kf[w][c], s, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dofr[c], vf[w][c], dp, 0, 0, 0);
+                }
+                const f32x4 l4 = *(const f32x4*)(lse_s + 16 * qt + 4 * g);
+                const f32x4 d4 = *(const f32x4*)(del_s + 16 * qt + 4 * g);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float pe = (t * FL_TILE + 16 * qt + 4 * g + e) < nq ? exp2f(s[e] * sc - l4[e]) : 0.f;
+                    pr[qt][e] = pe;
+                    ds[qt][e] = pe * (dp[e] - d4[e]);
+                }
+            }
+#pragma unroll
+            for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+                for (int q2 = 0; q2 < 2; ++q2) {
+                    dv[w][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<HD>(dos, q2, dt, g, qq, p), pack_pair(pr[2 * q2], pr[2 * q2 + 1]), dv[w][dt], 0, 0, 0);
+                    dk[w][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<HD>(qs, q2, dt, g, qq, p), pack_pair(ds[2 * q2], ds[2 * q2 + 1]), dk[w][dt], 0, 0, 0);
+                }
+        }
+        if (t + 1 < ntiles) {
+            char* nst = smem + ((t + 1) & 1) * STAGE_BYTES;
+            regs_to_tile<HD>(nst, (t + 1) * FL_TILE, nq, tid, qr);
+            regs_to_tile<HD>(nst + F::TILE_BYTES, (t + 1) * FL_TILE, nq, tid, dor);
+            store_stats(nst);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int w = 0; w < FL_W; ++w) {
+        const int key = k0 + 16 * w + fr;
+        if (key < nk) {
+#pragma unroll
+            for (int dt = 0; dt < C::DT; ++dt) {
+                const bf16x4 vv = {(bf16)dv[w][dt][0], (bf16)dv[w][dt][1], (bf16)dv[w][dt][2], (bf16)dv[w][dt][3]};
+                const bf16x4 kk = {(bf16)(dk[w][dt][0] * a.scale), (bf16)(dk[w][dt][1] * a.scale), (bf16)(dk[w][dt][2] * a.scale), (bf16)(dk[w][dt][3] * a.scale)};
+                *(bf16x4*)((bf16*)a.dv + b * a.dv_bs + (int64_t)key * a.dv_ts + hoff + dt * 16 + 4 * g) = vv;
+                *(bf16x4*)((bf16*)a.dk + b * a.dk_bs + (int64_t)key * a.dk_ts + hoff + dt * 16 + 4 * g) = kk;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+template <int HD>
+static int launch_flash_fwd(const AttnArgs& a, hipStream_t s) {
+    dim3 grid((unsigned)((a.nq + 64 * FL_W - 1) / (64 * FL_W)), (unsigned)a.heads, (unsigned)a.batch);
+    hipLaunchKernelGGL((attn_fwd_flash_kernel<HD>), grid, dim3(256), 4 * FlashCfg<HD>::TILE_BYTES, s, a);
+    return vited_check_launch();
+}
+
+template <int HD>
+static int launch_flash_bwd(const AttnArgs& a, hipStream_t s) {
+    dim3 gq((unsigned)((a.nq + 64 * FL_W - 1) / (64 * FL_W)), (unsigned)a.heads, (unsigned)a.batch);
+    dim3 gk((unsigned)((a.nk + 64 * FL_W - 1) / (64 * FL_W)), (unsigned)a.heads, (unsigned)a.batch);
+    hipLaunchKernelGGL((attn_bwd_dq_flash_kernel<HD>), gq, dim3(256), 4 * FlashCfg<HD>::TILE_BYTES, s, a);
+    hipLaunchKernelGGL((attn_bwd_dkv_flash_kernel<HD>), gk, dim3(256), 2 * (2 * FlashCfg<HD>::TILE_BYTES + 2 * FL_TILE * 4), s, a);
+    return vited_check_launch();
+}
+
+int attention_fwd_flash(const AttnArgs& a, hipStream_t s) {
+    if (a.head_dim == 32) return launch_flash_fwd<32>(a, s);
+    if (a.head_dim == 64) return launch_flash_fwd<64>(a, s);
+    return VITED_ERR_UNSUPPORTED;
+}
+
+int attention_bwd_flash(const AttnArgs& a, hipStream_t s) {
+    if (a.head_dim == 32) return launch_flash_bwd<32>(a, s);
+    if (a.head_dim == 64) return launch_flash_bwd<64>(a, s);
+    return VITED_ERR_UNSUPPORTED;
+}

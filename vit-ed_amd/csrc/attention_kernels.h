@@ -25,3 +25,7 @@ int attention_bwd_portable(const AttnArgs& a, int dtype, hipStream_t s);
 bool attention_mfma_supported(const AttnArgs& a, bool backward);
 int attention_fwd_mfma(const AttnArgs& a, hipStream_t s);
 int attention_bwd_mfma(const AttnArgs& a, hipStream_t s);
+
+// tiled online-softmax kernels for long sequences (attention_flash.hip)
+int attention_fwd_flash(const AttnArgs& a, hipStream_t s);
+int attention_bwd_flash(const AttnArgs& a, hipStream_t s);
