@@ -105,3 +105,69 @@ def test_scaler_call_shape_matches_reference():
     loss = torch.nn.functional.binary_cross_entropy_with_logits(model(x), y)
     norm = scaler(loss, opt, clip_grad=5.0, parameters=model.parameters(), update_grad=True)
     assert float(norm) > 0 and not torch.equal(before, model.head.weight) and scaler.state_dict()['scale'] == 1.0
+
+
+# ---------------------------------------------------------------------------------------------
+# pairwise similarity-matrix inference (BASELINE config 5; reference invariant: sharded == unsharded,
+# two-stage == one-shot, tests/hisfrag_evaluation_test.py:18-99,143)
+# ---------------------------------------------------------------------------------------------
+SIM_SHAPE = vo.ViTEDShape(img_size=32, patch_size=8, embed_dim=64, num_heads=2, depth=1, c_depth=1, num_classes=1)
+
+
+def _sim_images(n):
+    g = torch.Generator().manual_seed(7)
+    return torch.randn(n, 3, 32, 32, generator=g).clamp(-1, 1)
+
+
+def _naive_similarity(model, imgs):
+    n = imgs.shape[0]
+    i, j = torch.triu_indices(n, n)
+    with torch.no_grad():
+        logits = model(torch.stack([imgs[i], imgs[j]], dim=1)).reshape(-1)       # one-shot forward on stacked pairs
+    sim = torch.zeros(n, n, dtype=torch.float16)
+    sim[i, j] = logits.to(torch.float16)
+    sim[j, i] = logits.to(torch.float16)
+    return sim
+
+
+def test_row_sharding_balances_pairs():
+    from vited_amd import engine
+    for n, world in ((1, 1), (10, 3), (37, 8), (512, 8), (5, 8)):
+        b = engine.shard_rows_by_pair_count(n, world)
+        assert len(b) == world + 1 and b[0] == 0 and b[-1] == n and all(x <= y for x, y in zip(b, b[1:]))
+        counts = [sum(n - i for i in range(b[r], b[r + 1])) for r in range(world)]
+        assert sum(counts) == n * (n + 1) // 2
+        if n >= 4 * world:
+            assert max(counts) <= 1.5 * (sum(counts) / world) + n
+
+
+def _sim_worker(rank, world, port, out):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import vited_amd
+    from vited_amd import engine
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    engine.configure_ddp()
+    torch.manual_seed(3)
+    model = vo.OracleViTED(SIM_SHAPE)
+    sim = engine.pairwise_similarity(model, _sim_images(11), rank=rank, world=world, block=4, pair_batch=7, amp=False)
+    if rank == 1:
+        torch.save(sim, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_pairwise_similarity_sharded_equals_naive(tmp_path):
+    from vited_amd import engine
+    torch.manual_seed(3)
+    model = vo.OracleViTED(SIM_SHAPE)
+    imgs = _sim_images(11)
+    ref = _naive_similarity(model, imgs)
+    one = engine.pairwise_similarity(model, imgs, block=4, pair_batch=7, amp=False)
+    torch.testing.assert_close(one.float(), ref.float(), rtol=2e-3, atol=2e-3)
+    assert torch.equal(one, one.t())
+    out = str(tmp_path / 'sim.pt')
+    mp.spawn(_sim_worker, args=(2, 29900 + os.getpid() % 90, out), nprocs=2, join=True)
+    two = torch.load(out, weights_only=True)
+    assert torch.equal(two, one)            # 2 ranks + all-gather give bit-identical scores to 1 rank

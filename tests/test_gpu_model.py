@@ -223,3 +223,20 @@ def test_hisfrag_two_stage_training_step(vited, gpu):
     for n, p in model.named_parameters():
         err = (p.grad.cpu() - og[n].grad).norm() / (og[n].grad.norm() + 1e-12)
         assert err < 1e-3, f'{n}: {err:.3e}'
+
+
+def test_pairwise_similarity_matches_one_shot_pairs(vited, gpu):
+    """BASELINE config 5 on one rank: encoder once per image + decoder on gathered pairs (image-2 gather
+    inside the patch-embed kernel) == the naive one-shot forward on stacked pairs."""
+    s = vo.ViTEDShape(img_size=64, patch_size=8, num_classes=1, depth=1, c_depth=1)
+    model = vo.fill_closed_form_(_hip_model(vited, s, gpu, torch.bfloat16)).eval()
+    g = torch.Generator().manual_seed(5)
+    imgs = torch.randn(13, 3, 64, 64, generator=g).clamp(-1, 1).to(gpu)
+    sim = vited.engine.pairwise_similarity(model, imgs, block=5, pair_batch=16)
+    i, j = torch.triu_indices(13, 13, device=gpu)
+    with torch.no_grad():
+        ref = model(torch.stack([imgs[i], imgs[j]], dim=1)).reshape(-1)
+    torch.testing.assert_close(sim[i, j].float(), ref, rtol=2e-2, atol=2e-2)
+    assert torch.equal(sim, sim.t()) and sim.dtype == torch.float16
+    with pytest.raises(NotImplementedError):
+        model(model(imgs[:2], forward_first_part=True), imgs, x2_index=torch.tensor([0, 1], device=gpu))

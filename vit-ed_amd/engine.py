@@ -239,3 +239,84 @@ class TrainStep:
         self._g_opt = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._g_opt, pool=self._g_fb.pool()):
             self._static_norm = self._update()
+
+
+# ---------------------------------------------------------------------------------------------
+# pairwise similarity-matrix inference (hisfrag.py:161-302, BASELINE config 5)
+# ---------------------------------------------------------------------------------------------
+def shard_rows_by_pair_count(n: int, world: int):
+    """Contiguous row blocks of the upper triangle (i <= j) with ~equal PAIR counts per rank - the
+    balancing rule of data/samplers.py:108-137 in closed form.  Returns world+1 row boundaries."""
+    total = n * (n + 1) // 2
+    bounds, acc, r = [0], 0, 1
+    for i in range(n):
+        acc += n - i
+        while r < world and acc >= total * r / world:
+            bounds.append(i + 1)
+            r += 1
+    while len(bounds) < world + 1:
+        bounds.append(n)
+    bounds[-1] = n
+    return bounds
+
+
+@torch.no_grad()
+def pairwise_similarity(model, images, *, rank: int = 0, world: int = 1, block: int = 64, pair_batch: int = 512,
+                        amp: bool = True, group=None):
+    """similarity[i, j] = similarity[j, i] = fp16(logit(model(features(image_i), image_j))) for i <= j.
+
+    What hisfrag.py:161-302 computes, re-plumbed: the encoder runs ONCE per image of this rank's row
+    block, the decoder runs on `pair_batch` pairs at a time, image-2 gathers happen inside the
+    patch-embed kernel (index array, no materialised [P,3,S,S] copy - SURVEY section 7 last bullet), and
+    the ranks exchange their score vectors with ONE all-gather (RCCL on GPU) instead of the reference's
+    per-rank files + 120 s polling.  Every rank returns the full symmetric [n, n] fp16 matrix of raw
+    logits (callers take 1 - similarity as the distance, hisfrag.py:294-296)."""
+    n = images.shape[0]
+    dev = images.device
+    bounds = shard_rows_by_pair_count(n, world)
+    r0, r1 = bounds[rank], bounds[rank + 1]
+    dtype_ctx = torch.autocast(dev.type, dtype=torch.bfloat16, enabled=amp)
+    by_index = bool(getattr(model, 'supports_x2_index', False))
+    scores = []
+    was_training = model.training
+    model.eval()
+    for a0 in range(r0, r1, block):
+        a1 = min(a0 + block, r1)
+        with dtype_ctx:
+            feats = model(images[a0:a1], forward_first_part=True)          # encoder once per row block
+        ii, jj = torch.triu_indices(a1 - a0, n - a0, offset=0, device=dev)  # pairs (a0+ii, a0+jj), jj >= ii
+        for c0 in range(0, ii.numel(), pair_batch):
+            i_sub, j_sub = ii[c0:c0 + pair_batch], (jj[c0:c0 + pair_batch] + a0)
+            with dtype_ctx:
+                if by_index:
+                    out = model(feats[i_sub], images, x2_index=j_sub)
+                else:
+                    out = model(feats[i_sub], images[j_sub])
+            scores.append(out.float().reshape(-1))
+    mine = torch.cat(scores) if scores else torch.zeros(0, device=dev)
+    model.train(was_training)
+
+    # exchange: pad to the largest shard, one all-gather, then every rank rebuilds the matrix
+    counts = [sum(n - i for i in range(bounds[r], bounds[r + 1])) for r in range(world)]
+    if world > 1:
+        pad = torch.zeros(max(counts), dtype=torch.float32, device=dev)
+        pad[:mine.numel()] = mine
+        gathered = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(gathered, pad, group=group)
+    else:
+        gathered = [mine]
+    sim = torch.zeros((n, n), dtype=torch.float16, device=dev)
+    for r in range(world):
+        rows = torch.arange(bounds[r], bounds[r + 1], device=dev)
+        if rows.numel() == 0:
+            continue
+        # same enumeration order as the compute loop: row blocks of `block`, triu inside each block
+        off = 0
+        for a0 in range(bounds[r], bounds[r + 1], block):
+            a1 = min(a0 + block, bounds[r + 1])
+            ii, jj = torch.triu_indices(a1 - a0, n - a0, offset=0, device=dev)
+            vals = gathered[r][off: off + ii.numel()].to(torch.float16)
+            sim[ii + a0, jj + a0] = vals
+            sim[jj + a0, ii + a0] = vals
+            off += ii.numel()
+    return sim

@@ -254,13 +254,13 @@ class EncoderFn(torch.autograd.Function):
 # ---------------------------------------------------------------------------------------------
 class DecoderFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, rt: Runtime, feats, img2, *params):
+    def forward(ctx, rt: Runtime, feats, img2, img2_index, *params):
         pw, pb, pos, cls, gN, bN, wh, bh = params[:8]
         ns = 8
         nb = len(DEC_BLOCK_KEYS)
         blocks = [params[ns + i * nb: ns + (i + 1) * nb] for i in range(rt.c_depth)]
         grad = any(ctx.needs_input_grad)
-        x, patches, batch, n = _patch_tokens_fwd(rt, img2, pw, _bias(pb), pos, with_cls=True, cls=cls)
+        x, patches, batch, n = _patch_tokens_fwd(rt, img2, pw, _bias(pb), pos, with_cls=True, cls=cls, batch_index=img2_index)
         assert feats.shape == (batch, rt.n1, rt.dim), f'features {tuple(feats.shape)} do not match {batch} image-2 samples'
         ctxf = feats.detach().contiguous().float().view(batch * rt.n1, rt.dim)
         tape = []
@@ -349,4 +349,4 @@ class DecoderFn(torch.autograd.Function):
         grads[0], grads[1], grads[2], grads[3] = dpw, dpb, dpos, dcls.view_as(cls)
         dfeats = dctx.view(batch, rt.n1, d) if ctx.feats_needs_grad and dctx is not None else None
         ctx.tape = ctx.patches = ctx.ctxf = ctx.final = None
-        return (None, dfeats, None, *grads)
+        return (None, dfeats, None, None, *grads)

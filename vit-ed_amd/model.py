@@ -214,15 +214,21 @@ class VisionTransformerCustom(nn.Module):
         self._check_images(x1)
         return F_.EncoderFn.apply(self.runtime(), x1, *self._encoder_params())
 
-    def forward_second_part_head(self, x1_feats, x2):
-        self._check_images(x2)
-        return F_.DecoderFn.apply(self.runtime(), x1_feats, x2, *self._decoder_params())
+    supports_x2_index = True   # engine.pairwise_similarity gathers image-2 rows inside the patch-embed kernel
 
-    def forward(self, x, x2=None, forward_first_part=False):
+    def forward_second_part_head(self, x1_feats, x2, x2_index=None):
+        self._check_images(x2)
+        if x2_index is not None:
+            if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+                raise NotImplementedError('x2_index (gather-in-kernel) is an inference path: call it under torch.no_grad()')
+            x2_index = x2_index.to(device=x2.device, dtype=torch.int64).contiguous()
+        return F_.DecoderFn.apply(self.runtime(), x1_feats, x2, x2_index, *self._decoder_params())
+
+    def forward(self, x, x2=None, forward_first_part=False, x2_index=None):
         if forward_first_part:
             return self.forward_first_part(x)
         if x2 is not None:
-            return self.forward_second_part_head(x, x2)
+            return self.forward_second_part_head(x, x2, x2_index)
         if x.dim() != 5 or x.shape[1] != 2:
             raise AssertionError(f'expected stacked pairs [B, 2, C, S, S], got {tuple(x.shape)}')
         feats = self.forward_first_part(x[:, 0])      # strided views: the kernels take a batch stride
