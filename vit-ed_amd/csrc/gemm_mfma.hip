@@ -18,12 +18,15 @@
 #include "gemm_kernels.h"
 #include "gemm_nt_epilogue.h"
 
-#define BM 128
 #define BN 128
 // K-step depth per LDS stage: 64 (2 stages = 64 KB, 2 workgroups per CU) for long contractions,
 // 32 (2 stages = 32 KB, 4 workgroups per CU) for K <= 512 where a tile's life is only a few steps and
 // occupancy, not pipeline depth, is what hides HBM latency.
-template <int BKT> struct NtCfg {
+// WM = waves along M (each wave computes 64 x 64): 2 -> 128 x 128 tile / 256 threads, 4 -> 256 x 128 tile /
+// 512 threads.  The taller tile stages 25 % fewer operand bytes per FLOP through the LDS-DMA path, which is
+// what bounds these kernels.
+template <int BKT, int WM = 2> struct NtCfg {
+    static constexpr int BM = 64 * WM;
     static constexpr int ROW_BYTES = BKT * 2;
     static constexpr int A_BYTES = BM * ROW_BYTES;
     static constexpr int STAGE_BYTES = A_BYTES + BN * ROW_BYTES;
@@ -48,27 +51,33 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 // ---- NT stage: A tile [128 rows][BKT bf16] then B tile, each wave DMAs 32 rows of both ---------------
-template <int BKT>
+template <int BKT, int WM>
 __device__ __forceinline__ void nt_stage_load(const bf16* __restrict__ A, int64_t lda, const bf16* __restrict__ B,
                                               int64_t ldb, int64_t m0, int64_t n0, int64_t M, int64_t N, int64_t k0,
                                               char* stage, int wave, int lane) {
-    using C = NtCfg<BKT>;
+    using C = NtCfg<BKT, WM>;
     const int rsub = lane / C::CHUNKS, cp = lane % C::CHUNKS;
 #pragma unroll
-    for (int i = 0; i < 32 / C::ROWS_PER_DMA; ++i) {
+    for (int i = 0; i < 32 / C::ROWS_PER_DMA; ++i) {          // A: 32 rows per wave
         const int r = wave * 32 + i * C::ROWS_PER_DMA + rsub;
         const int c = cp ^ C::swz(r);
         int64_t gm = m0 + r;
         gm = gm < M ? gm : M - 1;
+        glds16(A + gm * lda + k0 + c * 8, stage + (wave * 32 + i * C::ROWS_PER_DMA) * C::ROW_BYTES);
+    }
+    constexpr int RB = BN / (2 * WM);                         // B: 128 rows over all waves
+#pragma unroll
+    for (int i = 0; i < RB / C::ROWS_PER_DMA; ++i) {
+        const int r = wave * RB + i * C::ROWS_PER_DMA + rsub;
+        const int c = cp ^ C::swz(r);
         int64_t gn = n0 + r;
         gn = gn < N ? gn : N - 1;
-        glds16(A + gm * lda + k0 + c * 8, stage + (wave * 32 + i * C::ROWS_PER_DMA) * C::ROW_BYTES);
-        glds16(B + gn * ldb + k0 + c * 8, stage + C::A_BYTES + (wave * 32 + i * C::ROWS_PER_DMA) * C::ROW_BYTES);
+        glds16(B + gn * ldb + k0 + c * 8, stage + C::A_BYTES + (wave * RB + i * C::ROWS_PER_DMA) * C::ROW_BYTES);
     }
 }
 
-template <int EPI, int BKT>
-__global__ void __launch_bounds__(256)
+template <int EPI, int BKT, int WM>
+__global__ void __launch_bounds__(128 * WM)
 gemm_nt_mfma_kernel(const bf16* __restrict__ A, int64_t lda, const bf16* __restrict__ B, int64_t ldb, int64_t M, int64_t N,
                     int64_t K, int tiles_n, int ntiles, EpiParams ep) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -76,7 +85,7 @@ gemm_nt_mfma_kernel(const bf16* __restrict__ A, int64_t lda, const bf16* __restr
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = wave >> 1, wc = wave & 1;
     const int tile = xcd_remap(blockIdx.x, ntiles);
-    const int64_t m0 = (int64_t)(tile / tiles_n) * BM, n0 = (int64_t)(tile % tiles_n) * BN;
+    const int64_t m0 = (int64_t)(tile / tiles_n) * (64 * WM), n0 = (int64_t)(tile % tiles_n) * BN;
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -84,9 +93,9 @@ gemm_nt_mfma_kernel(const bf16* __restrict__ A, int64_t lda, const bf16* __restr
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    using C = NtCfg<BKT>;
+    using C = NtCfg<BKT, WM>;
     const int nk = (int)(K / BKT);
-    nt_stage_load<BKT>(A, lda, B, ldb, m0, n0, M, N, 0, smem, wave, lane);
+    nt_stage_load<BKT, WM>(A, lda, B, ldb, m0, n0, M, N, 0, smem, wave, lane);
     const int fr = lane & 15, fq = lane >> 4;
     const int64_t mtile = m0 + wr * 64, ntile = n0 + wc * 64;
     EpiPrefetch<EPI> pf;
@@ -95,7 +104,7 @@ gemm_nt_mfma_kernel(const bf16* __restrict__ A, int64_t lda, const bf16* __restr
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();  // stage t landed for every wave; everyone is done reading stage t-1
         if (t + 1 < nk)
-            nt_stage_load<BKT>(A, lda, B, ldb, m0, n0, M, N, (int64_t)(t + 1) * BKT, smem + ((t + 1) & 1) * C::STAGE_BYTES, wave, lane);
+            nt_stage_load<BKT, WM>(A, lda, B, ldb, m0, n0, M, N, (int64_t)(t + 1) * BKT, smem + ((t + 1) & 1) * C::STAGE_BYTES, wave, lane);
         const char* sa = smem + (t & 1) * C::STAGE_BYTES;
         const char* sb = sa + C::A_BYTES;
 #pragma unroll
@@ -148,34 +157,48 @@ bool gemm_nt_mfma_supported(const void* A, int64_t lda, const void* B, int64_t l
     if (epilogue == VITED_EPI_GELU && !al16(ep.out2)) return false;
     if (epilogue == VITED_EPI_MUL_GELU_GRAD && !al16(ep.aux)) return false;
     if (epilogue == VITED_EPI_RESIDUAL && !al16(ep.residual)) return false;
-    if (ceil_div64(M, BM) * ceil_div64(N, BN) > (1 << 30)) return false;
+    if (ceil_div64(M, 128) * ceil_div64(N, BN) > (1 << 30)) return false;
     return true;
+}
+
+template <int EPI, int BKT, int WM>
+static void launch_nt(const bf16* a, int64_t lda, const bf16* b, int64_t ldb, int64_t M, int64_t N, int64_t K, const EpiParams& ep,
+                      hipStream_t s) {
+    using C = NtCfg<BKT, WM>;
+    const int tiles_n = (int)ceil_div64(N, BN);
+    const int ntiles = (int)ceil_div64(M, C::BM) * tiles_n;
+    auto kernel = gemm_nt_mfma_kernel<EPI, BKT, WM>;
+    hipLaunchKernelGGL(kernel, dim3(ntiles), dim3(128 * WM), 2 * C::STAGE_BYTES, s, a, lda, b, ldb, M, N, K, tiles_n, ntiles, ep);
+}
+
+template <int EPI>
+static void dispatch_nt(const bf16* a, int64_t lda, const bf16* b, int64_t ldb, int64_t M, int64_t N, int64_t K, const EpiParams& ep,
+                        hipStream_t s) {
+    // tuning/diagnostic overrides: VITED_NT_BK = 32 | 64, VITED_NT_WM = 2 | 4
+    static const int force_bk = getenv("VITED_NT_BK") ? atoi(getenv("VITED_NT_BK")) : 0;
+    static const int force_wm = getenv("VITED_NT_WM") ? atoi(getenv("VITED_NT_WM")) : 0;
+    const bool shallow = force_bk ? force_bk == 32 : K <= 512;
+    // measured (scratch/gemm_bench.py, M = 65536): the 256-row tile wins 5-10 % on plain-store K = 384 GEMMs with
+    // N >= 768 (qkv, kv, fc1) and loses on the register-heavier epilogues, so it is used only there
+    const bool tall = force_wm ? force_wm == 4 : (EPI == VITED_EPI_STORE && shallow && N >= 768 && M >= 8192);
+    if (shallow && tall) launch_nt<EPI, 32, 4>(a, lda, b, ldb, M, N, K, ep, s);
+    else if (shallow) launch_nt<EPI, 32, 2>(a, lda, b, ldb, M, N, K, ep, s);
+    else if (tall) launch_nt<EPI, 64, 4>(a, lda, b, ldb, M, N, K, ep, s);
+    else launch_nt<EPI, 64, 2>(a, lda, b, ldb, M, N, K, ep, s);
 }
 
 int gemm_nt_mfma(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K, int epilogue,
                  const EpiParams& ep, hipStream_t s) {
-    const int tiles_n = (int)ceil_div64(N, BN);
-    const int ntiles = (int)(ceil_div64(M, BM) * tiles_n);
     const bf16* a = (const bf16*)A;
     const bf16* b = (const bf16*)B;
-    static const int force_bk = getenv("VITED_NT_BK") ? atoi(getenv("VITED_NT_BK")) : 0;  // tuning/diagnostic override
-    const bool shallow = force_bk ? force_bk == 32 : K <= 512;
-#define LAUNCH_NT(E)                                                                                                        \
-    do {                                                                                                                    \
-        if (shallow)                                                                                                        \
-            hipLaunchKernelGGL((gemm_nt_mfma_kernel<E, 32>), dim3(ntiles), dim3(256), 2 * NtCfg<32>::STAGE_BYTES, s, a, lda, b, ldb, M, N, K, tiles_n, ntiles, ep); \
-        else                                                                                                                \
-            hipLaunchKernelGGL((gemm_nt_mfma_kernel<E, 64>), dim3(ntiles), dim3(256), 2 * NtCfg<64>::STAGE_BYTES, s, a, lda, b, ldb, M, N, K, tiles_n, ntiles, ep); \
-    } while (0)
     switch (epilogue) {
-        case VITED_EPI_STORE: LAUNCH_NT(VITED_EPI_STORE); break;
-        case VITED_EPI_GELU: LAUNCH_NT(VITED_EPI_GELU); break;
-        case VITED_EPI_RESIDUAL: LAUNCH_NT(VITED_EPI_RESIDUAL); break;
-        case VITED_EPI_MUL_GELU_GRAD: LAUNCH_NT(VITED_EPI_MUL_GELU_GRAD); break;
-        case VITED_EPI_STORE_F32: LAUNCH_NT(VITED_EPI_STORE_F32); break;
+        case VITED_EPI_STORE: dispatch_nt<VITED_EPI_STORE>(a, lda, b, ldb, M, N, K, ep, s); break;
+        case VITED_EPI_GELU: dispatch_nt<VITED_EPI_GELU>(a, lda, b, ldb, M, N, K, ep, s); break;
+        case VITED_EPI_RESIDUAL: dispatch_nt<VITED_EPI_RESIDUAL>(a, lda, b, ldb, M, N, K, ep, s); break;
+        case VITED_EPI_MUL_GELU_GRAD: dispatch_nt<VITED_EPI_MUL_GELU_GRAD>(a, lda, b, ldb, M, N, K, ep, s); break;
+        case VITED_EPI_STORE_F32: dispatch_nt<VITED_EPI_STORE_F32>(a, lda, b, ldb, M, N, K, ep, s); break;
         default: return VITED_ERR_BAD_ARG;
     }
-#undef LAUNCH_NT
     return vited_check_launch();
 }
 
