@@ -100,12 +100,13 @@ int vited_layernorm_fwd(const float* x, int64_t x_ld, const float* gamma, const 
                         float eps, void* stream);
 
 /* dx_out = (dx_in ? dx_in : 0) + LN'(dy); optional low-precision copy of dx_out (dx_lp, may be
- * null); dgamma/dbeta are OVERWRITTEN with the column sums.  workspace >= *_workspace_bytes. */
+ * null); dgamma/dbeta receive the column sums: overwritten, or added onto their current content when
+ * `accumulate` != 0 (accumulation straight into a parameter's .grad).  workspace >= *_workspace_bytes. */
 int64_t vited_layernorm_bwd_workspace_bytes(int64_t rows, int64_t dim);
 int vited_layernorm_bwd(const void* dy, int dy_dtype, int64_t dy_ld, const float* x, int64_t x_ld,
                         const float* gamma, const float* mean, const float* rstd, const float* dx_in,
                         int64_t dx_in_ld, float* dx_out, int64_t dx_out_ld, void* dx_lp, int dx_lp_dtype,
-                        int64_t dx_lp_ld, float* dgamma, float* dbeta, int64_t rows, int64_t dim,
+                        int64_t dx_lp_ld, float* dgamma, float* dbeta, int accumulate, int64_t rows, int64_t dim,
                         float* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- Linear / GEMM (nn.Linear: qkv :34, proj :38, q :151, kv :152, timm Mlp fc1/fc2, head) ---- */
@@ -125,11 +126,12 @@ int vited_gemm(const void* A, int64_t lda, const void* B, int64_t ldb, int b_lay
                const float* residual, void* out, void* out2, int64_t ldo, int64_t rows_per_batch,
                int64_t out_rows_per_batch, int64_t row_offset, int residual_bcast, void* stream);
 
-/* dW[n, k] = sum_m dY[m, n] * X[m, k] (fp32 [N, K], OVERWRITTEN) and, if dbias != null,
- * dbias[n] = sum_m dY[m, n].  dY / X are `dtype`.  workspace >= *_workspace_bytes. */
+/* dW[n, k] = sum_m dY[m, n] * X[m, k] (fp32 [N, K]) and, if dbias != null, dbias[n] = sum_m dY[m, n];
+ * overwritten, or added onto their current content when `accumulate` != 0.  dY / X are `dtype`.
+ * workspace >= *_workspace_bytes. */
 int64_t vited_linear_bwd_weight_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int vited_linear_bwd_weight(const void* dY, int64_t lddy, const void* X, int64_t ldx, int dtype, int64_t M,
-                            int64_t N, int64_t K, float* dW, float* dbias, float* workspace,
+                            int64_t N, int64_t K, float* dW, float* dbias, int accumulate, float* workspace,
                             int64_t workspace_bytes, void* stream);
 
 /* ---- attention core (F.scaled_dot_product_attention, vision_transformer.py:63-66,183-186) ----- */

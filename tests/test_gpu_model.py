@@ -240,3 +240,26 @@ def test_pairwise_similarity_matches_one_shot_pairs(vited, gpu):
     assert torch.equal(sim, sim.t()) and sim.dtype == torch.float16
     with pytest.raises(NotImplementedError):
         model(model(imgs[:2], forward_first_part=True), imgs, x2_index=torch.tensor([0, 1], device=gpu))
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_direct_gradient_accumulation_matches_autograd(vited, gpu, dtype):
+    """engine.FlatGradients mode: the weight-gradient / LayerNorm kernels add straight into p.grad (views of
+    one flat buffer) instead of returning tensors for autograd to accumulate.  Same numbers, and a second
+    backward accumulates (ACCUMULATION_STEPS > 1, misc/engine.py:202-231)."""
+    s = vo.ViTEDShape(depth=2, c_depth=2)
+    torch.manual_seed(2)
+    ref = _hip_model(vited, s, gpu, dtype)
+    dut = _hip_model(vited, s, gpu, dtype)
+    dut.load_state_dict(ref.state_dict())
+    x = torch.randn(6, 2, 3, 64, 64, device=gpu).clamp(-1, 1)
+    y = (torch.rand(6, 4, device=gpu) > 0.75).float()
+    torch.nn.functional.binary_cross_entropy_with_logits(ref(x), y).backward()
+    flat = vited.engine.FlatGradients(dut.parameters())
+    dut.direct_param_grads = True
+    for rep in (1, 2):
+        torch.nn.functional.binary_cross_entropy_with_logits(dut(x), y).backward()
+        assert vited.ops.last_paths()[0] in (1, 2)
+        for (n, p), (_, q) in zip(ref.named_parameters(), dut.named_parameters()):
+            assert q.grad.data_ptr() >= flat.flat.data_ptr() and q.grad.data_ptr() < flat.flat.data_ptr() + flat.flat.numel() * 4, n
+            torch.testing.assert_close(q.grad, rep * p.grad, rtol=1e-4, atol=1e-6 * float(p.grad.abs().max() + 1), msg=lambda m: f'{n}: {m}')

@@ -35,12 +35,12 @@ SIGNATURES = {
     'vited_sum_rows': (_i, [_p, _i, _i64, _p, _i64, _i64, _p, _i64, _p]),
     'vited_layernorm_fwd': (_i, [_p, _i64, _p, _p, _p, _i, _i64, _p, _p, _i64, _i64, _f, _p]),
     'vited_layernorm_bwd_workspace_bytes': (_i64, [_i64, _i64]),
-    'vited_layernorm_bwd': (_i, [_p, _i, _i64, _p, _i64, _p, _p, _p, _p, _i64, _p, _i64, _p, _i, _i64, _p, _p,
+    'vited_layernorm_bwd': (_i, [_p, _i, _i64, _p, _i64, _p, _p, _p, _p, _i64, _p, _i64, _p, _i, _i64, _p, _p, _i,
                                  _i64, _i64, _p, _i64, _p]),
     'vited_gemm': (_i, [_p, _i64, _p, _i64, _i, _i, _i64, _i64, _i64, _i, _p, _p, _p, _p, _p, _i64, _i64, _i64,
                         _i64, _i, _p]),
     'vited_linear_bwd_weight_workspace_bytes': (_i64, [_i64, _i64, _i64]),
-    'vited_linear_bwd_weight': (_i, [_p, _i64, _p, _i64, _i, _i64, _i64, _i64, _p, _p, _p, _i64, _p]),
+    'vited_linear_bwd_weight': (_i, [_p, _i64, _p, _i64, _i, _i64, _i64, _i64, _p, _p, _i, _p, _i64, _p]),
     'vited_attention_fwd': (_i, [_p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _p, _i, _i64, _i,
                                  _i64, _i64, _i, _f, _p]),
     'vited_attention_bwd': (_i, [_p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _p, _p, _i64, _i64, _p, _p,

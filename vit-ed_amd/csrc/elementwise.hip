@@ -224,7 +224,36 @@ extern "C" int vited_sum_rows(const void* in, int in_dtype, int64_t in_ld, float
     return vited_check_launch();
 }
 
-int sum_rows_f32_single_pass(const float* in, int64_t in_ld, float* out, int64_t batch, int64_t width, hipStream_t s) {
-    hipLaunchKernelGGL((sum_rows_kernel<float>), dim3((unsigned)ceil_div64(width, 256), 1), dim3(256), 0, s, in, in_ld, out, batch, width, batch);
+// out[r] (+)= sum_b in[b, r] in one pass; accumulate = add onto what out already holds (gradient accumulation
+// straight into a parameter's .grad, see vited_linear_bwd_weight)
+__global__ void sum_slabs_kernel(const float* __restrict__ in, int64_t in_ld, float* __restrict__ out, int64_t batch, int64_t width,
+                                 int accumulate) {
+    const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (r >= width) return;
+    if (r + 3 < width) {
+        f32x4 acc = accumulate ? *(const f32x4*)(out + r) : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int64_t b = 0; b < batch; ++b) {
+            const f32x4 v = *(const f32x4*)(in + b * in_ld + r);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += v[e];
+        }
+        *(f32x4*)(out + r) = acc;
+    } else {
+        for (int64_t c = r; c < width; ++c) {
+            float acc = accumulate ? out[c] : 0.f;
+            for (int64_t b = 0; b < batch; ++b) acc += in[b * in_ld + c];
+            out[c] = acc;
+        }
+    }
+}
+
+int sum_rows_f32_single_pass(const float* in, int64_t in_ld, float* out, int64_t batch, int64_t width, hipStream_t s, int accumulate) {
+    const bool vec = (width % 4 == 0) && (in_ld % 4 == 0) && ((((uintptr_t)in) | ((uintptr_t)out)) & 15) == 0;
+    if (vec)
+        hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)ceil_div64(width, 1024)), dim3(256), 0, s, in, in_ld, out, batch, width, accumulate);
+    else if (!accumulate)
+        hipLaunchKernelGGL((sum_rows_kernel<float>), dim3((unsigned)ceil_div64(width, 256), 1), dim3(256), 0, s, in, in_ld, out, batch, width, batch);
+    else
+        return VITED_ERR_UNSUPPORTED;
     return vited_check_launch();
 }

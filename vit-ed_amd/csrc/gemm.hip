@@ -64,11 +64,11 @@ static inline int64_t max64(int64_t a, int64_t b) { return a > b ? a : b; }
 extern "C" int64_t vited_linear_bwd_weight_workspace_bytes(int64_t M, int64_t N, int64_t K) {
     const int64_t s = max64(tn_portable_splits(M, N, K), gemm_tn_mfma_splits(M, N, K));
     // slabs for dW + the row-sum workspace for dbias (placed after the slabs)
-    return (s * N * K + s * N) * (int64_t)sizeof(float) + vited_sum_rows_workspace_bytes(M, N) + 256;
+    return (s * N * K + s * N + N) * (int64_t)sizeof(float) + vited_sum_rows_workspace_bytes(M, N) + 256;
 }
 
 extern "C" int vited_linear_bwd_weight(const void* dY, int64_t lddy, const void* X, int64_t ldx, int dtype, int64_t M,
-                                       int64_t N, int64_t K, float* dW, float* dbias, float* workspace,
+                                       int64_t N, int64_t K, float* dW, float* dbias, int accumulate, float* workspace,
                                        int64_t workspace_bytes, void* stream) {
     if (!dY || !X || !dW || M <= 0 || N <= 0 || K <= 0 || lddy < N || ldx < K) return VITED_ERR_BAD_ARG;
     if (dtype != VITED_F32 && dtype != VITED_BF16) return VITED_ERR_UNSUPPORTED;
@@ -76,31 +76,38 @@ extern "C" int vited_linear_bwd_weight(const void* dY, int64_t lddy, const void*
     hipStream_t s = (hipStream_t)stream;
     const bool mfma = dtype == VITED_BF16 && gemm_tn_mfma_supported(dY, lddy, X, ldx, M, N, K);
     const int64_t splits = mfma ? gemm_tn_mfma_splits(M, N, K) : tn_portable_splits(M, N, K);
-    float* slab = splits > 1 ? workspace : dW;
+    // partial products always go to workspace slabs when accumulating (the sum pass adds onto dW / dbias)
+    const bool via_slabs = splits > 1 || accumulate;
+    float* slab = via_slabs ? workspace : dW;
+    float* bias_tmp = workspace + splits * N * K;            // [splits][N] (MFMA) or [N] (portable)
     int rc;
     if (mfma) {
         g_last_gemm_path = 2;
-        float* bias_slab = !dbias ? nullptr : (splits > 1 ? workspace + splits * N * K : dbias);
+        float* bias_slab = !dbias ? nullptr : (via_slabs ? bias_tmp : dbias);
         rc = gemm_tn_mfma(dY, lddy, X, ldx, M, N, K, splits, slab, bias_slab, s);
         if (rc != VITED_OK) return rc;
-        if (splits > 1) {
-            rc = sum_rows_f32_single_pass(workspace, N * K, dW, splits, N * K, s);
-            if (rc == VITED_OK && dbias) rc = sum_rows_f32_single_pass(bias_slab, N, dbias, splits, N, s);
+        if (via_slabs) {
+            rc = sum_rows_f32_single_pass(workspace, N * K, dW, splits, N * K, s, accumulate);
+            if (rc == VITED_OK && dbias) rc = sum_rows_f32_single_pass(bias_slab, N, dbias, splits, N, s, accumulate);
         }
         return rc;
-    } else {
-        g_last_gemm_path = 1;
-        rc = gemm_tn_portable(dY, lddy, X, ldx, dtype, M, N, K, splits, slab, s);
     }
+    g_last_gemm_path = 1;
+    rc = gemm_tn_portable(dY, lddy, X, ldx, dtype, M, N, K, splits, slab, s);
     if (rc != VITED_OK) return rc;
-    if (splits > 1) {  // dW = sum of the slabs (single pass: few slabs, N*K wide)
-        rc = sum_rows_f32_single_pass(workspace, N * K, dW, splits, N * K, s);
+    if (via_slabs) {
+        rc = sum_rows_f32_single_pass(workspace, N * K, dW, splits, N * K, s, accumulate);
         if (rc != VITED_OK) return rc;
     }
     if (dbias) {
-        float* ws2 = workspace + splits * N * K;
-        const int64_t ws2_bytes = workspace_bytes - splits * N * K * (int64_t)sizeof(float);
-        rc = vited_sum_rows(dY, dtype, lddy, dbias, M, N, ws2, ws2_bytes, stream);
+        float* ws2 = bias_tmp + N;
+        const int64_t ws2_bytes = workspace_bytes - (splits * N * K + N) * (int64_t)sizeof(float);
+        if (accumulate) {
+            rc = vited_sum_rows(dY, dtype, lddy, bias_tmp, M, N, ws2, ws2_bytes, stream);
+            if (rc == VITED_OK) rc = sum_rows_f32_single_pass(bias_tmp, N, dbias, 1, N, s, 1);
+        } else {
+            rc = vited_sum_rows(dY, dtype, lddy, dbias, M, N, ws2, ws2_bytes, stream);
+        }
     }
     return rc;
 }

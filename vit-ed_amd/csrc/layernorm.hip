@@ -221,7 +221,7 @@ layernorm_bwd_kernel(const T* __restrict__ dy, int64_t dy_ld, const float* __res
 // group and step), LDS combine: 4x more workgroups and 4x shorter loops than a 64-column block
 __global__ void __launch_bounds__(256)
 ln_bwd_finish_kernel(const float* __restrict__ partial, int nparts, int width, float* __restrict__ dgamma,
-                     float* __restrict__ dbeta, int dim) {
+                     float* __restrict__ dbeta, int dim, int accumulate) {
     __shared__ float red[16][17];
     const int cx = threadIdx.x & 15, py = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cx;
@@ -240,7 +240,8 @@ ln_bwd_finish_kernel(const float* __restrict__ partial, int nparts, int width, f
         float v = 0.f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) v += red[k][cx];
-        if (c < dim) dgamma[c] = v; else dbeta[c - dim] = v;
+        float* dst = c < dim ? dgamma + c : dbeta + (c - dim);
+        *dst = accumulate ? *dst + v : v;
     }
 }
 
@@ -258,7 +259,7 @@ extern "C" int64_t vited_layernorm_bwd_workspace_bytes(int64_t rows, int64_t dim
 template <typename T>
 static int ln_bwd_launch(const void* dy, int64_t dy_ld, const float* x, int64_t x_ld, const float* gamma, const float* mean,
                          const float* rstd, const float* dx_in, int64_t dx_in_ld, float* dx_out, int64_t dx_out_ld, void* dx_lp,
-                         int64_t dx_lp_ld, float* dgamma, float* dbeta, int64_t rows, int dim, float* ws, hipStream_t s) {
+                         int64_t dx_lp_ld, float* dgamma, float* dbeta, int accumulate, int64_t rows, int dim, float* ws, hipStream_t s) {
     const int64_t blocks = ln_bwd_blocks(rows);
     const size_t lds = (size_t)8 * 2 * dim * sizeof(float);
     const int vpl = (int)ceil_div64(dim, 128);
@@ -275,14 +276,14 @@ static int ln_bwd_launch(const void* dy, int64_t dy_ld, const float* x, int64_t 
         default: L(8); break;
     }
 #undef L
-    hipLaunchKernelGGL(ln_bwd_finish_kernel, dim3((2 * dim + 15) / 16), dim3(256), 0, s, ws, (int)blocks, 2 * dim, dgamma, dbeta, dim);
+    hipLaunchKernelGGL(ln_bwd_finish_kernel, dim3((2 * dim + 15) / 16), dim3(256), 0, s, ws, (int)blocks, 2 * dim, dgamma, dbeta, dim, accumulate);
     return vited_check_launch();
 }
 
 extern "C" int vited_layernorm_bwd(const void* dy, int dy_dtype, int64_t dy_ld, const float* x, int64_t x_ld,
                                    const float* gamma, const float* mean, const float* rstd, const float* dx_in,
                                    int64_t dx_in_ld, float* dx_out, int64_t dx_out_ld, void* dx_lp, int dx_lp_dtype,
-                                   int64_t dx_lp_ld, float* dgamma, float* dbeta, int64_t rows, int64_t dim,
+                                   int64_t dx_lp_ld, float* dgamma, float* dbeta, int accumulate, int64_t rows, int64_t dim,
                                    float* workspace, int64_t workspace_bytes, void* stream) {
     if (!dy || !x || !gamma || !mean || !rstd || !dx_out || !dgamma || !dbeta || rows <= 0 || dim <= 0) return VITED_ERR_BAD_ARG;
     if (!ln_shape_ok(dim, x_ld, dy_ld, dx_out_ld) || (dx_in && dx_in_ld % 4) || (dx_lp && dx_lp_ld % 4)) return VITED_ERR_UNSUPPORTED;
@@ -294,8 +295,8 @@ extern "C" int vited_layernorm_bwd(const void* dy, int dy_dtype, int64_t dy_ld, 
     hipStream_t s = (hipStream_t)stream;
     const int d = (int)dim;
     if (dy_dtype == VITED_BF16)
-        return ln_bwd_launch<bf16>(dy, dy_ld, x, x_ld, gamma, mean, rstd, dx_in, dx_in_ld, dx_out, dx_out_ld, dx_lp, dx_lp_ld, dgamma, dbeta, rows, d, workspace, s);
+        return ln_bwd_launch<bf16>(dy, dy_ld, x, x_ld, gamma, mean, rstd, dx_in, dx_in_ld, dx_out, dx_out_ld, dx_lp, dx_lp_ld, dgamma, dbeta, accumulate, rows, d, workspace, s);
     if (dy_dtype == VITED_F32)
-        return ln_bwd_launch<float>(dy, dy_ld, x, x_ld, gamma, mean, rstd, dx_in, dx_in_ld, dx_out, dx_out_ld, dx_lp, dx_lp_ld, dgamma, dbeta, rows, d, workspace, s);
+        return ln_bwd_launch<float>(dy, dy_ld, x, x_ld, gamma, mean, rstd, dx_in, dx_in_ld, dx_out, dx_out_ld, dx_lp, dx_lp_ld, dgamma, dbeta, accumulate, rows, d, workspace, s);
     return VITED_ERR_UNSUPPORTED;
 }

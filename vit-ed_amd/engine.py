@@ -171,6 +171,8 @@ class TrainStep:
         self.model, self.optimizer, self.clip_grad, self.amp = model, optimizer, clip_grad, amp
         self.criterion = criterion or torch.nn.BCEWithLogitsLoss()
         self.flat = FlatGradients(model.parameters(), compress_bf16=compress_bf16)
+        if hasattr(model, 'direct_param_grads') or hasattr(model, 'runtime'):
+            model.direct_param_grads = True     # HIP model: weight-gradient kernels add straight into the flat buffer
         self.forward_fn = forward_fn or (lambda m, x: m(x))
         self.use_graph = use_graph and torch.cuda.is_available()
         self._g_fb = self._g_opt = None

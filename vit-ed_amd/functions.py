@@ -46,6 +46,7 @@ class Runtime:
         self.head_dim = embed_dim // num_heads
         self.scale = self.head_dim ** -0.5
         self.act_dtype = act_dtype
+        self.direct_grads = False   # accumulate parameter gradients straight into existing p.grad (engine.FlatGradients)
         self._shadow = {}
 
     @property
@@ -101,7 +102,38 @@ def _lp(rt: Runtime, t_f32: torch.Tensor) -> torch.Tensor:
 # ---------------------------------------------------------------------------------------------
 # shared pieces
 # ---------------------------------------------------------------------------------------------
-def _linear_bwd(rt, dy, x_saved, w, want_dx=True, aux=None):
+def _gtarget(rt, p):
+    """p.grad when gradients may be accumulated straight into it (saves autograd's AccumulateGrad add and
+    a temporary per parameter): only when the caller pre-attached dense fp32 .grad tensors."""
+    if p is None or not rt.direct_grads:
+        return None
+    g = p.grad
+    if g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.shape != p.shape or g.device != p.device:
+        return None
+    return g
+
+
+def _ln_bwd(rt, dy, x, gamma, beta, mean, rstd, **kw):
+    """LayerNorm backward; returns (dx, dx_lp, dgamma | None, dbeta | None) - None when accumulated in place."""
+    gg, gb = _gtarget(rt, gamma), _gtarget(rt, beta)
+    if gg is not None and gb is not None:
+        dx, dx_lp, _, _ = ops.layernorm_bwd(dy, x, gamma, mean, rstd, dgamma=gg, dbeta=gb, **kw)
+        return dx, dx_lp, None, None
+    return ops.layernorm_bwd(dy, x, gamma, mean, rstd, **kw)
+
+
+def _weight_grads(rt, dy, x_saved, w, b):
+    """(dW | None, db | None) of y = x W^T + b; None when accumulated straight into w.grad / b.grad."""
+    gw = _gtarget(rt, w)
+    gb = _gtarget(rt, b) if b is not None else None
+    if gw is not None and (b is None or gb is not None):
+        ops.linear_bwd_weight(dy, x_saved, want_bias=b is not None, dw_out=gw.view(gw.shape[0], -1), db_out=gb)
+        return None, None
+    dw, db = ops.linear_bwd_weight(dy, x_saved)
+    return dw.view_as(w), (db if b is not None else None)
+
+
+def _linear_bwd(rt, dy, x_saved, w, b=None, want_dx=True, aux=None):
     """(dx | None, dW, db) of y = x W^T + b given dy (activation dtype)."""
     dx = None
     if want_dx:
@@ -110,8 +142,8 @@ def _linear_bwd(rt, dy, x_saved, w, want_dx=True, aux=None):
             dx = ops.gemm(dy, wt, b_layout=layout, epilogue=EPI_MUL_GELU_GRAD, aux=aux)
         else:
             dx = ops.gemm(dy, wt, b_layout=layout)
-    dw, db = ops.linear_bwd_weight(dy, x_saved)
-    return dx, dw.view_as(w), db
+    dw, db = _weight_grads(rt, dy, x_saved, w, b)
+    return dx, dw, db
 
 
 def _self_attn_fwd(rt, h, wqkv, bqkv, batch, n):
@@ -140,11 +172,11 @@ def _mlp_fwd(rt, x, g, b, w1, b1, w2, b2):
     return y, (mean, rstd, h, z, u)
 
 
-def _mlp_bwd(rt, dy, dy_lp, x, g, w1, w2, saved):
+def _mlp_bwd(rt, dy, dy_lp, x, g, b, w1, b1, w2, b2, saved):
     mean, rstd, h, z, u = saved
-    dz, dw2, db2 = _linear_bwd(rt, dy_lp, u, w2, aux=z)
-    dh, dw1, db1 = _linear_bwd(rt, dz, h, w1)
-    dx, dx_lp, dg, db = ops.layernorm_bwd(dh, x, g, mean, rstd, dx_in=dy, want_lp=not rt.exact)
+    dz, dw2, db2 = _linear_bwd(rt, dy_lp, u, w2, b2, aux=z)
+    dh, dw1, db1 = _linear_bwd(rt, dz, h, w1, b1)
+    dx, dx_lp, dg, db = _ln_bwd(rt, dh, x, g, b, mean, rstd, dx_in=dy, want_lp=not rt.exact)
     return dx, (dx if rt.exact else dx_lp), (dg, db, dw1, db1, dw2, db2)
 
 
@@ -155,12 +187,12 @@ def _attn_branch_fwd(rt, x, g, b, wqkv, bqkv, wproj, bproj, batch, n):
     return y, (mean, rstd, h, qkv, o, lse)
 
 
-def _attn_branch_bwd(rt, dy, dy_lp, x, g, wqkv, wproj, saved, batch, n):
+def _attn_branch_bwd(rt, dy, dy_lp, x, g, b, wqkv, bqkv, wproj, bproj, saved, batch, n):
     mean, rstd, h, qkv, o, lse = saved
-    do, dwp, dbp = _linear_bwd(rt, dy_lp, o, wproj)
+    do, dwp, dbp = _linear_bwd(rt, dy_lp, o, wproj, bproj)
     dqkv = _self_attn_bwd(rt, do, qkv, o, lse, batch, n)
-    dh, dwq, dbq = _linear_bwd(rt, dqkv, h, wqkv)
-    dx, dx_lp, dg, db = ops.layernorm_bwd(dh, x, g, mean, rstd, dx_in=dy, want_lp=not rt.exact)
+    dh, dwq, dbq = _linear_bwd(rt, dqkv, h, wqkv, bqkv)
+    dx, dx_lp, dg, db = _ln_bwd(rt, dh, x, g, b, mean, rstd, dx_in=dy, want_lp=not rt.exact)
     return dx, (dx if rt.exact else dx_lp), (dg, db, dwq, dbq, dwp, dbp)
 
 
@@ -180,7 +212,7 @@ def _patch_tokens_fwd(rt, img, pw, pb, pos, with_cls, cls=None, batch_index=None
     return x, patches, batch, rows
 
 
-def _patch_tokens_bwd(rt, dx, patches, pw, pos, with_cls, batch):
+def _patch_tokens_bwd(rt, dx, patches, pw, pb, pos, with_cls, batch):
     """dx fp32 [B*rows, D] -> (d patch weight, d patch bias, d pos_embed, d cls | None)."""
     rows = rt.n2 if with_cls else rt.n1
     dx3 = dx.view(batch, rows, rt.dim)
@@ -194,8 +226,8 @@ def _patch_tokens_bwd(rt, dx, patches, pw, pos, with_cls, batch):
     else:
         dpos[0, 1:] = dpos_rows
         dtok = dx if rt.exact else ops.cast(dx, rt.act_dtype)
-    dw, db = ops.linear_bwd_weight(dtok, patches)
-    return dw.view_as(pw), db, dpos, dcls
+    dw, db = _weight_grads(rt, dtok, patches, pw, pb)
+    return dw, db, dpos, dcls
 
 
 def _bias(b):
@@ -238,12 +270,12 @@ class EncoderFn(torch.autograd.Function):
             g1, b1, wqkv, bqkv, wproj, bproj, g2, b2, w1, bb1, w2, bb2 = params[3 + i * nb: 3 + (i + 1) * nb]
             x, sa, xa, sm = ctx.tape[i]
             ctx.tape[i] = None
-            dx, dx_lp, (dg2, db2, dw1, dbb1, dw2, dbb2) = _mlp_bwd(rt, dx, dx_lp, xa, g2, w1, w2, sm)
-            dx, dx_lp, (dg1, db1, dwq, dbq, dwp, dbp) = _attn_branch_bwd(rt, dx, dx_lp, x, g1, wqkv, wproj, sa, batch, n)
+            dx, dx_lp, (dg2, db2, dw1, dbb1, dw2, dbb2) = _mlp_bwd(rt, dx, dx_lp, xa, g2, b2, w1, bb1, w2, bb2, sm)
+            dx, dx_lp, (dg1, db1, dwq, dbq, dwp, dbp) = _attn_branch_bwd(rt, dx, dx_lp, x, g1, b1, wqkv, bqkv, wproj, bproj, sa, batch, n)
             base = 3 + i * nb
-            blk = [dg1, db1, dwq, dbq if bqkv is not None else None, dwp, dbp, dg2, db2, dw1, dbb1, dw2, dbb2]
+            blk = [dg1, db1, dwq, dbq, dwp, dbp, dg2, db2, dw1, dbb1, dw2, dbb2]
             grads[base: base + nb] = blk
-        dpw, dpb, dpos, _ = _patch_tokens_bwd(rt, dx, ctx.patches, pw, pos, with_cls=False, batch=batch)
+        dpw, dpb, dpos, _ = _patch_tokens_bwd(rt, dx, ctx.patches, pw, pb, pos, with_cls=False, batch=batch)
         grads[0], grads[1], grads[2] = dpw, dpb, dpos
         ctx.tape = ctx.patches = None
         return (None, None, *grads)
@@ -303,7 +335,7 @@ class DecoderFn(torch.autograd.Function):
         dl = _lp(rt, dlogits.contiguous().float())
         wh_act = rt.weight(wh)
         dy = ops.gemm(dl, wh_act, b_layout=B_KN)                         # [B, D]
-        dwh, dbh = ops.linear_bwd_weight(dl, y)
+        dwh, dbh = _weight_grads(rt, dl, y, wh, bh)
         # final LayerNorm touches the cls rows only; every other row of d(x) is zero
         dx = torch.zeros((batch * n, d), dtype=torch.float32, device=dy.device)
         dx3 = dx.view(batch, n, d)
@@ -312,11 +344,10 @@ class DecoderFn(torch.autograd.Function):
         if not rt.exact:
             dx_lp = torch.zeros((batch * n, d), dtype=rt.act_dtype, device=dy.device)
             dx_lp3 = dx_lp.view(batch, n, d)[:, 0, :]
-        _, _, dgN, dbN = ops.layernorm_bwd(dy, x.view(batch, n, d)[:, 0, :], gN, mN, rN, dx_out=dx3[:, 0, :],
-                                           dx_lp=dx_lp3)
+        _, _, dgN, dbN = _ln_bwd(rt, dy, x.view(batch, n, d)[:, 0, :], gN, bN, mN, rN, dx_out=dx3[:, 0, :], dx_lp=dx_lp3)
         if rt.exact:
             dx_lp = dx
-        grads[4], grads[5], grads[6], grads[7] = dgN, dbN, dwh.view_as(wh), dbh if bh is not None else None
+        grads[4], grads[5], grads[6], grads[7] = dgN, dbN, dwh, dbh
         dctx = None
         for i in reversed(range(rt.c_depth)):
             (g1, b1, wqkv, bqkv, wproj, bproj, gc, bc, gx, bx, wq, bq, wkv, bkv, wcp, bcp, g2, b2, w1, bb1, w2,
@@ -324,28 +355,27 @@ class DecoderFn(torch.autograd.Function):
             x, sa, xa, sc, xb, sm = ctx.tape[i]
             ctx.tape[i] = None
             mq, rq, hq, mc, rc, hc, q, kv, oc, lse_c = sc
-            dx, dx_lp, (dg2, db2, dw1, dbb1, dw2, dbb2) = _mlp_bwd(rt, dx, dx_lp, xb, g2, w1, w2, sm)
+            dx, dx_lp, (dg2, db2, dw1, dbb1, dw2, dbb2) = _mlp_bwd(rt, dx, dx_lp, xb, g2, b2, w1, bb1, w2, bb2, sm)
             # cross attention
-            doc, dwcp, dbcp = _linear_bwd(rt, dx_lp, oc, wcp)
+            doc, dwcp, dbcp = _linear_bwd(rt, dx_lp, oc, wcp, bcp)
             dq = torch.empty_like(q)
             dkv = torch.empty_like(kv)
             kv3, dkv3 = kv.view(batch, rt.n1, 2 * d), dkv.view(batch, rt.n1, 2 * d)
             ops.attention_bwd(q.view(batch, n, d), kv3[:, :, 0:d], kv3[:, :, d:2 * d], oc.view(batch, n, d),
                               doc.view(batch, n, d), lse_c, rt.heads, rt.scale, dq.view(batch, n, d), dkv3[:, :, 0:d],
                               dkv3[:, :, d:2 * d])
-            dhq, dwq, dbq = _linear_bwd(rt, dq, hq, wq)
-            dhc, dwkv, dbkv = _linear_bwd(rt, dkv, hc, wkv)
-            dx, dx_lp, dgc, dbc = ops.layernorm_bwd(dhq, xa, gc, mq, rq, dx_in=dx, want_lp=not rt.exact)
+            dhq, dwq, dbq = _linear_bwd(rt, dq, hq, wq, bq)
+            dhc, dwkv, dbkv = _linear_bwd(rt, dkv, hc, wkv, bkv)
+            dx, dx_lp, dgc, dbc = _ln_bwd(rt, dhq, xa, gc, bc, mq, rq, dx_in=dx, want_lp=not rt.exact)
             if rt.exact:
                 dx_lp = dx
             # d(context) accumulates over the c_depth blocks in fp32, in place
-            dctx, _, dgx, dbx = ops.layernorm_bwd(dhc, ctx.ctxf, gx, mc, rc, dx_in=dctx, dx_out=dctx)
-            dx, dx_lp, (dg1, db1, dwqkv, dbqkv, dwp, dbp) = _attn_branch_bwd(rt, dx, dx_lp, x, g1, wqkv, wproj, sa, batch, n)
+            dctx, _, dgx, dbx = _ln_bwd(rt, dhc, ctx.ctxf, gx, bx, mc, rc, dx_in=dctx, dx_out=dctx)
+            dx, dx_lp, (dg1, db1, dwqkv, dbqkv, dwp, dbp) = _attn_branch_bwd(rt, dx, dx_lp, x, g1, b1, wqkv, bqkv, wproj, bproj, sa, batch, n)
             base = ns + i * nb
-            grads[base: base + nb] = [dg1, db1, dwqkv, dbqkv if bqkv is not None else None, dwp, dbp, dgc, dbc, dgx, dbx,
-                                      dwq, dbq if bq is not None else None, dwkv, dbkv if bkv is not None else None, dwcp,
-                                      dbcp, dg2, db2, dw1, dbb1, dw2, dbb2]
-        dpw, dpb, dpos, dcls = _patch_tokens_bwd(rt, dx, ctx.patches, pw, pos, with_cls=True, batch=batch)
+            grads[base: base + nb] = [dg1, db1, dwqkv, dbqkv, dwp, dbp, dgc, dbc, dgx, dbx, dwq, dbq, dwkv, dbkv, dwcp, dbcp,
+                                      dg2, db2, dw1, dbb1, dw2, dbb2]
+        dpw, dpb, dpos, dcls = _patch_tokens_bwd(rt, dx, ctx.patches, pw, pb, pos, with_cls=True, batch=batch)
         grads[0], grads[1], grads[2], grads[3] = dpw, dpb, dpos, dcls.view_as(cls)
         dfeats = dctx.view(batch, rt.n1, d) if ctx.feats_needs_grad and dctx is not None else None
         ctx.tape = ctx.patches = ctx.ctxf = ctx.final = None

@@ -188,6 +188,7 @@ class VisionTransformerCustom(nn.Module):
                          num_classes=self.num_classes, embed_dim=self.embed_dim, depth=self.depth, c_depth=self.c_depth,
                          num_heads=self.num_heads, act_dtype=dt)
             self._runtimes[dt] = rt
+        rt.direct_grads = bool(getattr(self, 'direct_param_grads', False))
         return rt
 
     def _encoder_params(self):

@@ -152,8 +152,10 @@ def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps:
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dx_in=None, dx_out=None, want_lp: bool = False, dx_lp=None):
-    """Returns (dx fp32, dx_lp bf16 | None, dgamma, dbeta).
+def layernorm_bwd(dy, x, gamma, mean, rstd, dx_in=None, dx_out=None, want_lp: bool = False, dx_lp=None, dgamma=None,
+                  dbeta=None):
+    """Returns (dx fp32, dx_lp bf16 | None, dgamma, dbeta).  When ``dgamma`` / ``dbeta`` are given (fp32,
+    contiguous - e.g. views of the flat gradient buffer) the column sums are ADDED onto them.
 
     dx = (dx_in or 0) + LN'(dy).  ``dx_out`` / ``dx_lp`` may be given as pre-made (row-strided)
     destinations - e.g. the cls rows of a zero-filled token-gradient tensor."""
@@ -168,14 +170,18 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dx_in=None, dx_out=None, want_lp: bo
         dx_lp = torch.empty((rows, dim), dtype=torch.bfloat16, device=x.device)
     if dx_in is not None:
         assert dx_in.dtype == torch.float32 and dx_in.shape == x.shape
-    dgamma = torch.empty(dim, dtype=torch.float32, device=x.device)
-    dbeta = torch.empty(dim, dtype=torch.float32, device=x.device)
+    accumulate = dgamma is not None
+    if accumulate:
+        assert dbeta is not None and dgamma.dtype == dbeta.dtype == torch.float32 and dgamma.is_contiguous() and dbeta.is_contiguous()
+    else:
+        dgamma = torch.empty(dim, dtype=torch.float32, device=x.device)
+        dbeta = torch.empty(dim, dtype=torch.float32, device=x.device)
     nbytes = lib.vited_layernorm_bwd_workspace_bytes(rows, dim)
     ws = workspace(nbytes, x.device)
     _lib.check(lib.vited_layernorm_bwd(
         _ptr(dy), _code(dy.dtype), dy_ld, _ptr(x), x_ld, _ptr(gamma), _ptr(mean), _ptr(rstd),
         _ptr(dx_in), _rows2d(dx_in) if dx_in is not None else 0, _ptr(dx_out), _rows2d(dx_out),
-        _ptr(dx_lp), BF16, _rows2d(dx_lp) if dx_lp is not None else 0, _ptr(dgamma), _ptr(dbeta), rows, dim,
+        _ptr(dx_lp), BF16, _rows2d(dx_lp) if dx_lp is not None else 0, _ptr(dgamma), _ptr(dbeta), int(accumulate), rows, dim,
         _ptr(ws), ws.numel() * 4, _stream()), 'vited_layernorm_bwd')
     return dx_out, dx_lp, dgamma, dbeta
 
@@ -217,20 +223,27 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, b_layout: int = B_NK, epilogue: in
     return (out, out2) if epilogue == EPI_GELU else out
 
 
-def linear_bwd_weight(dy: torch.Tensor, x: torch.Tensor, want_bias: bool = True):
-    """dW[N,K] = dy[M,N]^T x[M,K] (fp32), dbias[N] = column sums of dy (fp32) or None."""
+def linear_bwd_weight(dy: torch.Tensor, x: torch.Tensor, want_bias: bool = True, dw_out=None, db_out=None):
+    """dW[N,K] = dy[M,N]^T x[M,K] (fp32), dbias[N] = column sums of dy (fp32) or None.  With ``dw_out``
+    (and ``db_out``) the results are ADDED onto those fp32 tensors (a parameter's .grad) instead."""
     _need_gpu(dy, x)
     assert dy.dtype == x.dtype and dy.shape[0] == x.shape[0]
     lddy, ldx = _rows2d(dy), _rows2d(x)
     m, n = dy.shape
     k = x.shape[1]
     lib = _lib.load()
-    dw = torch.empty((n, k), dtype=torch.float32, device=x.device)
-    db = torch.empty(n, dtype=torch.float32, device=x.device) if want_bias else None
+    accumulate = dw_out is not None
+    if accumulate:
+        assert dw_out.dtype == torch.float32 and dw_out.is_contiguous() and dw_out.numel() == n * k
+        dw, db = dw_out, (db_out if want_bias else None)
+        assert db is None or (db.dtype == torch.float32 and db.is_contiguous() and db.numel() == n)
+    else:
+        dw = torch.empty((n, k), dtype=torch.float32, device=x.device)
+        db = torch.empty(n, dtype=torch.float32, device=x.device) if want_bias else None
     nbytes = lib.vited_linear_bwd_weight_workspace_bytes(m, n, k)
     ws = workspace(nbytes, x.device)
     _lib.check(lib.vited_linear_bwd_weight(_ptr(dy), lddy, _ptr(x), ldx, _code(x.dtype), m, n, k, _ptr(dw), _ptr(db),
-                                           _ptr(ws), ws.numel() * 4, _stream()), 'vited_linear_bwd_weight')
+                                           int(accumulate), _ptr(ws), ws.numel() * 4, _stream()), 'vited_linear_bwd_weight')
     return dw, db
 
 
