@@ -226,13 +226,19 @@ extern "C" int vited_sum_rows(const void* in, int in_dtype, int64_t in_ld, float
 
 // out[r] (+)= sum_b in[b, r] in one pass; accumulate = add onto what out already holds (gradient accumulation
 // straight into a parameter's .grad, see vited_linear_bwd_weight)
-__global__ void sum_slabs_kernel(const float* __restrict__ in, int64_t in_ld, float* __restrict__ out, int64_t batch, int64_t width,
-                                 int accumulate) {
-    const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+__device__ __forceinline__ void sum_slabs_body(const float* __restrict__ in, int64_t in_ld, float* __restrict__ out, int64_t batch,
+                                               int64_t width, int accumulate, int64_t r) {
     if (r >= width) return;
     if (r + 3 < width) {
         f32x4 acc = accumulate ? *(const f32x4*)(out + r) : f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int64_t b = 0; b < batch; ++b) {
+        int64_t b = 0;
+        for (; b + 4 <= batch; b += 4) {   // four independent 16-B loads in flight per lane
+            const f32x4 v0 = *(const f32x4*)(in + b * in_ld + r), v1 = *(const f32x4*)(in + (b + 1) * in_ld + r);
+            const f32x4 v2 = *(const f32x4*)(in + (b + 2) * in_ld + r), v3 = *(const f32x4*)(in + (b + 3) * in_ld + r);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += (v0[e] + v1[e]) + (v2[e] + v3[e]);
+        }
+        for (; b < batch; ++b) {
             const f32x4 v = *(const f32x4*)(in + b * in_ld + r);
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[e] += v[e];
@@ -247,6 +253,23 @@ __global__ void sum_slabs_kernel(const float* __restrict__ in, int64_t in_ld, fl
     }
 }
 
+__global__ void sum_slabs_kernel(const float* __restrict__ in, int64_t in_ld, float* __restrict__ out, int64_t batch, int64_t width,
+                                 int accumulate) {
+    sum_slabs_body(in, in_ld, out, batch, width, accumulate, ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4);
+}
+
+// two slab sets of one split-K launch (dW and dbias) reduced by ONE launch: blocks [0, blocks_a) take set A
+__global__ void sum_slabs_pair_kernel(const float* __restrict__ in_a, int64_t ld_a, float* __restrict__ out_a, int64_t width_a,
+                                      int blocks_a, const float* __restrict__ in_b, int64_t ld_b, float* __restrict__ out_b,
+                                      int64_t width_b, int64_t batch, int accumulate) {
+    if ((int)blockIdx.x < blocks_a)
+        sum_slabs_body(in_a, ld_a, out_a, batch, width_a, accumulate, ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4);
+    else
+        sum_slabs_body(in_b, ld_b, out_b, batch, width_b, accumulate,
+                       ((int64_t)(blockIdx.x - blocks_a) * blockDim.x + threadIdx.x) * 4);
+}
+
+
 int sum_rows_f32_single_pass(const float* in, int64_t in_ld, float* out, int64_t batch, int64_t width, hipStream_t s, int accumulate) {
     const bool vec = (width % 4 == 0) && (in_ld % 4 == 0) && ((((uintptr_t)in) | ((uintptr_t)out)) & 15) == 0;
     if (vec)
@@ -255,5 +278,20 @@ int sum_rows_f32_single_pass(const float* in, int64_t in_ld, float* out, int64_t
         hipLaunchKernelGGL((sum_rows_kernel<float>), dim3((unsigned)ceil_div64(width, 256), 1), dim3(256), 0, s, in, in_ld, out, batch, width, batch);
     else
         return VITED_ERR_UNSUPPORTED;
+    return vited_check_launch();
+}
+
+int sum_slabs_pair(const float* in_a, int64_t ld_a, float* out_a, int64_t width_a, const float* in_b, int64_t ld_b, float* out_b,
+                   int64_t width_b, int64_t batch, hipStream_t s, int accumulate) {
+    const bool vec = (width_a % 4 == 0) && (ld_a % 4 == 0) && (width_b % 4 == 0) && (ld_b % 4 == 0) &&
+                     ((((uintptr_t)in_a) | ((uintptr_t)out_a) | ((uintptr_t)in_b) | ((uintptr_t)out_b)) & 15) == 0;
+    if (!vec) {
+        int rc = sum_rows_f32_single_pass(in_a, ld_a, out_a, batch, width_a, s, accumulate);
+        if (rc == VITED_OK) rc = sum_rows_f32_single_pass(in_b, ld_b, out_b, batch, width_b, s, accumulate);
+        return rc;
+    }
+    const int ba = (int)ceil_div64(width_a, 1024), bb = (int)ceil_div64(width_b, 1024);
+    hipLaunchKernelGGL(sum_slabs_pair_kernel, dim3((unsigned)(ba + bb)), dim3(256), 0, s, in_a, ld_a, out_a, width_a, ba, in_b, ld_b,
+                       out_b, width_b, batch, accumulate);
     return vited_check_launch();
 }

@@ -87,8 +87,8 @@ extern "C" int vited_linear_bwd_weight(const void* dY, int64_t lddy, const void*
         rc = gemm_tn_mfma(dY, lddy, X, ldx, M, N, K, splits, slab, bias_slab, s);
         if (rc != VITED_OK) return rc;
         if (via_slabs) {
-            rc = sum_rows_f32_single_pass(workspace, N * K, dW, splits, N * K, s, accumulate);
-            if (rc == VITED_OK && dbias) rc = sum_rows_f32_single_pass(bias_slab, N, dbias, splits, N, s, accumulate);
+            rc = dbias ? sum_slabs_pair(workspace, N * K, dW, N * K, bias_slab, N, dbias, N, splits, s, accumulate)
+                       : sum_rows_f32_single_pass(workspace, N * K, dW, splits, N * K, s, accumulate);
         }
         return rc;
     }

@@ -240,7 +240,7 @@ __device__ __forceinline__ void tn_stage_load(const bf16* __restrict__ dY, int64
 }
 
 template <bool BIAS>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3)))   // 3 workgroups/CU: <= 168 VGPRs
 gemm_tn_mfma_kernel(const bf16* __restrict__ dY, int64_t lddy, const bf16* __restrict__ X, int64_t ldx, int64_t M, int64_t N,
                     int64_t K, int64_t rows_per_split, int tiles_k, float* __restrict__ out, float* __restrict__ bias_out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -256,19 +256,14 @@ gemm_tn_mfma_kernel(const bf16* __restrict__ dY, int64_t lddy, const bf16* __res
     const int64_t mb = (int64_t)split * rows_per_split;
     int64_t me = mb + rows_per_split;
     me = me < M ? me : M;
-    // bias rows are dealt round-robin over the (k-tile, wave-column) pairs that share an n-range, so no
-    // workgroup carries the whole extra MFMA load (a straggler would set the kernel time)
-    const int bias_pair = (tile_id % tiles_k) * 2 + wc, bias_pairs = tiles_k * 2;   // wave-uniform
 
-    f32x4 acc[4][4], accb[4];
+    f32x4 acc[4][4];
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};   // dbias partials: this lane's 8 m-rows of dY column (lane & 15) of block i
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    const bf16 one = (bf16)1.0f;
-    const bf16x8 ones = {one, one, one, one, one, one, one, one};
 
     const int nsteps = me > mb ? (int)((me - mb + TM - 1) / TM) : 0;
     if (nsteps > 0) tn_stage_load(dY, lddy, X, ldx, mb, me - 1, n0, N, kc0, K, smem, wave, lane);
@@ -317,10 +312,17 @@ gemm_tn_mfma_kernel(const bf16* __restrict__ dY, int64_t lddy, const bf16* __res
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf_[j], acc[i][j], 0, 0, 0);
-            if constexpr (BIAS) {
+            if (BIAS && kc0 == 0) {
+                // column sums of dY on the VALU (v_dot2_f32_bf16 against packed ones), branch-free so the MFMA
+                // schedule is untouched: an MFMA-by-ones variant and a dealt (conditional) one both cost 70-100 VGPRs
+                typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+                const bf16x2_t one2 = {(__bf16)1.0f, (__bf16)1.0f};
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (i % bias_pairs == bias_pair) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, accb[i], 0, 0, 0);
+                for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        bsum[i] = __builtin_amdgcn_fdot2_f32_bf16(bf16x2_t{af[i][2 * e], af[i][2 * e + 1]}, one2, bsum[i], false);
+                }
             }
         }
     }
@@ -338,17 +340,18 @@ gemm_tn_mfma_kernel(const bf16* __restrict__ dY, int64_t lddy, const bf16* __res
             }
         }
     }
-    if (BIAS && fr == 0) {
-        float* bo = bias_out + (int64_t)split * N;
+    if constexpr (BIAS) {
+        if (kc0 == 0 && wc == 0) {   // every k-tile / wave column holds the same sums: one of them stores
+            float* bo = bias_out + (int64_t)split * N;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (i % bias_pairs == bias_pair) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int64_t n = n0 + wr * 64 + i * 16 + fq * 4 + e;
-                    if (n < N) bo[n] = accb[i][e];
-                }
+            for (int i = 0; i < 4; ++i) {
+                float v = bsum[i];
+                v += __shfl_xor(v, 16);
+                v += __shfl_xor(v, 32);
+                const int64_t n = n0 + wr * 64 + i * 16 + fr;
+                if (fq == 0 && n < N) bo[n] = v;
             }
+        }
     }
 }
 
