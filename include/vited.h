@@ -68,6 +68,15 @@ int vited_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t
  * by the input-gradient GEMMs. */
 int vited_cast_transpose(const float* src, void* dst, int dst_dtype, int64_t rows, int64_t cols, void* stream);
 
+/* Refresh every bf16 weight shadow of a model in ONE launch (after an optimizer step; replaces one
+ * vited_cast + one vited_cast_transpose per weight).  desc is a DEVICE array of count x 6 int64:
+ *   {src fp32 [rows, cols] address, dst bf16 [rows, cols] address or 0, dst_t bf16 [cols, rows] address or 0,
+ *    rows, cols, first_tile}
+ * where first_tile is the running sum of ceil(rows/64) * ceil(cols/64) over the preceding entries and
+ * total_tiles the sum over all of them.  The reference has no counterpart: under autocast PyTorch
+ * re-casts each weight inside every F.linear call (vision_transformer.py:49-80 via misc/engine.py:208). */
+int vited_cast_weights(const int64_t* desc, int count, int64_t total_tiles, void* stream);
+
 /* Patch extraction for timm PatchEmbed's Conv2d(k = s = p) (used at vision_transformer.py:383,391):
  * out[(b * G*G + py*G + px), (c*p + i)*p + j] = img[idx(b), c, py*p + i, px*p + j]
  * img is fp32 with batch stride img_bs (so x[:, 0] / x[:, 1] of the stacked pair tensor need no

@@ -33,6 +33,28 @@ def test_cast_and_transpose(vited, gpu):
         assert torch.equal(ops.cast_transpose(w, torch.float32), w.t().contiguous())
 
 
+def test_cast_weights_multi_tensor_matches_single_casts(vited, gpu):
+    """vited_cast_weights: every shadow of every weight in one launch, bit-equal to the per-weight casts."""
+    ops = vited.ops
+    shapes = [(384, 1152), (4, 384), (384, 192), (100, 36), (65, 130), (1536, 384), (64, 64), (1, 8)]
+    ws = [_rand(sh, gpu, 7 + i) for i, sh in enumerate(shapes)]
+    entries = []
+    for i, w in enumerate(ws):
+        n = torch.full(w.shape, 7.0, device=gpu, dtype=torch.bfloat16) if i % 3 != 1 else None
+        t = torch.full((w.shape[1], w.shape[0]), 7.0, device=gpu, dtype=torch.bfloat16) if i % 3 != 2 else None
+        entries.append((w, n, t))
+    plan = ops.WeightShadowPlan(entries)
+    for rnd in range(2):   # second round: weights changed in place, same plan
+        plan.run()
+        for w, n, t in entries:
+            if n is not None:
+                assert torch.equal(n, w.to(torch.bfloat16))
+            if t is not None:
+                assert torch.equal(t, w.t().contiguous().to(torch.bfloat16))
+        for w in ws:
+            w.mul_(1.5).add_(0.25)
+
+
 @pytest.mark.parametrize('S,p,C', [(64, 8, 3), (64, 32, 3), (128, 16, 3), (32, 8, 1)])
 def test_patchify_matches_unfold(vited, gpu, S, p, C):
     ops = vited.ops

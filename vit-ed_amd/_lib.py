@@ -28,6 +28,7 @@ SIGNATURES = {
     'vited_last_attention_path': (_i, []),
     'vited_cast': (_i, [_p, _i, _p, _i, _i64, _p]),
     'vited_cast_transpose': (_i, [_p, _p, _i, _i64, _i64, _p]),
+    'vited_cast_weights': (_i, [_p, _i, _i64, _p]),
     'vited_patchify': (_i, [_p, _i64, _p, _p, _i, _i64, _i, _i, _i, _p]),
     'vited_slice_rows_cast': (_i, [_p, _p, _i, _i64, _i64, _i64, _i64, _i64, _p]),
     'vited_write_cls_row': (_i, [_p, _p, _p, _i64, _i64, _i64, _p]),

@@ -73,6 +73,80 @@ extern "C" int vited_cast_transpose(const float* src, void* dst, int dst_dtype, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Multi-tensor weight-shadow refresh: every fp32 master weight [rows, cols] -> its bf16 [rows, cols]
+// and / or transposed bf16 [cols, rows] shadow in ONE launch (was ~180 launches per optimizer step).
+// desc[t] = {src, dst (0 = none), dst_t (0 = none), rows, cols, first_tile}; one workgroup per 64x64 tile.
+// ------------------------------------------------------------------------------------------------
+#define WS_DESC_WORDS 6
+__global__ void __launch_bounds__(256)
+cast_weights_kernel(const int64_t* __restrict__ desc, int count) {
+    __shared__ bf16 tile[64][66];   // 33-dword rows: the transposed read walks 64 different banks
+    const int64_t blk = blockIdx.x;
+    int lo = 0, hi = count - 1;     // last descriptor whose first_tile <= blk
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (desc[(int64_t)mid * WS_DESC_WORDS + 5] <= blk) lo = mid; else hi = mid - 1;
+    }
+    const int64_t* d = desc + (int64_t)lo * WS_DESC_WORDS;
+    const float* __restrict__ src = (const float*)d[0];
+    bf16* __restrict__ dst = (bf16*)d[1];
+    bf16* __restrict__ dst_t = (bf16*)d[2];
+    const int64_t rows = d[3], cols = d[4];
+    const int64_t t = blk - d[5], tiles_c = (cols + 63) >> 6;
+    const int64_t r0 = (t / tiles_c) << 6, c0 = (t % tiles_c) << 6;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;   // 16 x 16: 4 columns x 4 rows per thread
+    const bool vec = (cols & 3) == 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int lr = ty + 16 * j;
+        const int64_t r = r0 + lr, c = c0 + tx * 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (r < rows) {
+            if (vec && c + 3 < cols) {
+                const f32x4 q = *(const f32x4*)(src + r * cols + c);
+                v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (c + e < cols) v[e] = src[r * cols + c + e];
+            }
+        }
+        bf16 b[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { b[e] = (bf16)v[e]; tile[lr][tx * 4 + e] = b[e]; }
+        if (dst && r < rows) {
+            if (vec && c + 3 < cols) *(bf16x4*)(dst + r * cols + c) = bf16x4{b[0], b[1], b[2], b[3]};
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (c + e < cols) dst[r * cols + c + e] = b[e];
+            }
+        }
+    }
+    if (!dst_t) return;
+    __syncthreads();
+    const bool vec_t = (rows & 3) == 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int lc = ty + 16 * j;                 // column of the source tile = row of the transposed shadow
+        const int64_t c = c0 + lc, r = r0 + tx * 4;
+        if (c >= cols) continue;
+        bf16 b[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) b[e] = tile[tx * 4 + e][lc];
+        if (vec_t && r + 3 < rows) *(bf16x4*)(dst_t + c * rows + r) = bf16x4{b[0], b[1], b[2], b[3]};
+        else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (r + e < rows) dst_t[c * rows + r + e] = b[e];
+        }
+    }
+}
+
+extern "C" int vited_cast_weights(const int64_t* desc, int count, int64_t total_tiles, void* stream) {
+    if (!desc || count <= 0 || total_tiles <= 0 || total_tiles > 0x7fffffff) return VITED_ERR_BAD_ARG;
+    hipLaunchKernelGGL(cast_weights_kernel, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream, desc, count);
+    return vited_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------
 // patchify: one workgroup per (image, patch-row py): it reads p full image rows per channel
 // (coalesced along x) and writes the G patch rows of the token matrix.
 // ------------------------------------------------------------------------------------------------

@@ -81,18 +81,28 @@ class Runtime:
         return ent[2]
 
     def refresh_shadows(self, params):
-        """Recast every cached shadow in place (call after an optimizer step when replaying a graph)."""
+        """Recast every cached shadow in place with ONE multi-tensor launch (call after an optimizer step when
+        replaying a graph: the captured kernels keep reading the same shadow buffers)."""
         by_id = {id(p): p for p in params}
-        for (pid, tag), ent in list(self._shadow.items()):
-            p = by_id.get(pid)
-            if p is None:
-                continue
-            w2 = p.detach().reshape(p.shape[0], -1)
-            if tag == 'n':
-                ops.cast(w2, self.act_dtype, out=ent[2])
-            else:
-                ops.cast_transpose(w2.contiguous(), self.act_dtype, out=ent[2])
-            self._shadow[(pid, tag)] = (p._version, p.data_ptr(), ent[2])
+        per_param = {}
+        for (pid, tag), ent in self._shadow.items():
+            if pid in by_id:
+                per_param.setdefault(pid, {})[tag] = ent[2]
+        entries = []
+        for pid, tags in per_param.items():
+            p = by_id[pid]
+            entries.append((p.detach().reshape(p.shape[0], -1), tags.get('n'), tags.get('t')))
+        if not entries:
+            return
+        key = tuple((w.data_ptr(), 0 if n is None else n.data_ptr(), 0 if t is None else t.data_ptr()) for w, n, t in entries)
+        plan = getattr(self, '_shadow_plan', None)
+        if plan is None or plan.key != key:
+            plan = self._shadow_plan = ops.WeightShadowPlan(entries)
+        plan.run()
+        for pid, tags in per_param.items():
+            p = by_id[pid]
+            for tag, buf in tags.items():
+                self._shadow[(pid, tag)] = (p._version, p.data_ptr(), buf)
 
 
 def _lp(rt: Runtime, t_f32: torch.Tensor) -> torch.Tensor:

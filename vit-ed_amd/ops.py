@@ -84,6 +84,34 @@ def cast_transpose(w: torch.Tensor, dtype: torch.dtype, out: torch.Tensor | None
     return out
 
 
+class WeightShadowPlan:
+    """Device descriptor table for ``vited_cast_weights``: built once per set of (weight, shadow, transposed
+    shadow) buffers, then every refresh is one launch."""
+
+    def __init__(self, entries):
+        """entries: iterable of (w fp32 [rows, cols] contiguous, dst bf16 [rows, cols] | None, dst_t bf16 [cols, rows] | None)."""
+        rows_, keep, tile = [], [], 0
+        for w, dst, dst_t in entries:
+            _need_gpu(w, dst, dst_t)
+            assert w.dtype == torch.float32 and w.dim() == 2 and w.is_contiguous() and w.data_ptr() % 16 == 0
+            r, c = w.shape
+            for t, shape in ((dst, (r, c)), (dst_t, (c, r))):
+                assert t is None or (t.dtype == torch.bfloat16 and tuple(t.shape) == shape and t.is_contiguous()
+                                     and t.data_ptr() % 16 == 0)
+            if dst is None and dst_t is None:
+                continue
+            rows_.append([w.data_ptr(), _ptr(dst), _ptr(dst_t), r, c, tile])
+            tile += ((r + 63) // 64) * ((c + 63) // 64)
+            keep.append((w, dst, dst_t))
+        self.count, self.total_tiles, self._keep = len(rows_), tile, keep
+        self.key = tuple(tuple(r[:3]) for r in rows_)
+        self.table = torch.tensor(rows_, dtype=torch.int64).to(keep[0][0].device) if rows_ else None
+
+    def run(self):
+        if self.count:
+            _lib.check(_lib.load().vited_cast_weights(_ptr(self.table), self.count, self.total_tiles, _stream()), 'vited_cast_weights')
+
+
 def patchify(img: torch.Tensor, patch: int, dtype: torch.dtype, batch_index: torch.Tensor | None = None) -> torch.Tensor:
     """img fp32 [B, C, S, S] (any batch stride, dense [C, S, S]) -> [B * (S/p)^2, C*p*p]."""
     _need_gpu(img, batch_index)
