@@ -157,8 +157,13 @@ layernorm_bwd_kernel(const T* __restrict__ dy, int64_t dy_ld, const float* __res
         const float mu = mean[r], rs = rstd[r];
         const T* dyr = dy + r * dy_ld;
         const float* xr = x + r * x_ld;
-        f32x4 xh[VPL], gg[VPL];
+        f32x4 xh[VPL], gg[VPL], res[VPL];
         float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) {   // the incoming residual gradient rides along with the first loads, not behind the row sums
+            const int c = (j * 32 + hl) * 4;
+            res[j] = (dx_in && c < dim) ? *(const f32x4*)(dx_in + r * dx_in_ld + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
         for (int j = 0; j < VPL; ++j) {
             const int c = (j * 32 + hl) * 4;
@@ -186,12 +191,7 @@ layernorm_bwd_kernel(const T* __restrict__ dy, int64_t dy_ld, const float* __res
             if (c < dim) {
                 f32x4 v;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = rs * (gg[j][e] - c1 - xh[j][e] * c2);
-                if (dx_in) {
-                    const f32x4 a = *(const f32x4*)(dx_in + r * dx_in_ld + c);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += a[e];
-                }
+                for (int e = 0; e < 4; ++e) v[e] = rs * (gg[j][e] - c1 - xh[j][e] * c2) + res[j][e];
                 *(f32x4*)(dx_out + r * dx_out_ld + c) = v;
                 if (dx_lp) Vec4<bf16>::store(dx_lp + r * dx_lp_ld + c, v);
             }
@@ -247,7 +247,7 @@ ln_bwd_finish_kernel(const float* __restrict__ partial, int nparts, int width, f
 
 static inline int64_t ln_bwd_blocks(int64_t rows) {
     int64_t b = ceil_div64(rows, 8 * 4);  // >= 4 rows per half-wave
-    if (b > 512) b = 512;
+    if (b > 768) b = 768;                 // 3 workgroups per CU: measured best of 512 / 768 / 1024 / 1536 / 2048 at 66,560 rows
     if (b < 1) b = 1;
     return b;
 }
