@@ -42,34 +42,46 @@ __device__ __forceinline__ void remap_rows(const EpiParams& p, int64_t m, int64_
 
 // mtile = first row of the wave's 64-row slab, ntile = first column of its 64-column slab
 template <int EPI>
-__device__ __forceinline__ void epilogue_prefetch(const EpiParams& p, EpiPrefetch<EPI>& pf, int64_t mtile, int64_t ntile, int64_t M,
-                                                  int64_t N, int lane) {
+__device__ __forceinline__ void epilogue_prefetch_bias(const EpiParams& p, EpiPrefetch<EPI>& pf, int64_t ntile, int64_t N, int lane) {
     using T = EpiTraits<EPI>;
     const int64_t n = ntile + T::col(lane);
     const bool ncol = n < N;
     pf.bias[0] = (p.bias && ncol) ? *(const f32x4*)(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
     pf.bias[1] = (p.bias && ncol && T::WIDTH == 8) ? *(const f32x4*)(p.bias + n + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// residual / saved pre-activation of the 16-row sub-tile i
+template <int EPI>
+__device__ __forceinline__ void epilogue_prefetch_subtile(const EpiParams& p, EpiPrefetch<EPI>& pf, int i, int64_t mtile, int64_t ntile,
+                                                          int64_t M, int64_t N, int lane) {
+    using T = EpiTraits<EPI>;
+    const int64_t n = ntile + T::col(lane);
+    const bool ncol = n < N;
     if constexpr (EPI == VITED_EPI_RESIDUAL) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int pc = 0; pc < 4; ++pc) {
-                const int64_t m = mtile + i * 16 + T::row(lane, pc);
-                int64_t orow, rrow;
-                remap_rows(p, m, orow, rrow);
-                pf.res[i][pc] = (m < M && ncol) ? *(const f32x4*)(p.residual + rrow * p.ldo + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
+        for (int pc = 0; pc < 4; ++pc) {
+            const int64_t m = mtile + i * 16 + T::row(lane, pc);
+            int64_t orow, rrow;
+            remap_rows(p, m, orow, rrow);
+            pf.res[i][pc] = (m < M && ncol) ? *(const f32x4*)(p.residual + rrow * p.ldo + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
     }
     if constexpr (EPI == VITED_EPI_MUL_GELU_GRAD) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int pc = 0; pc < 2; ++pc) {
-                const int64_t m = mtile + i * 16 + T::row(lane, pc);
-                pf.aux[i][pc] = (m < M && ncol) ? *(const bf16x8*)((const bf16*)p.aux + m * p.ldo + n)
-                                                : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-            }
+        for (int pc = 0; pc < 2; ++pc) {
+            const int64_t m = mtile + i * 16 + T::row(lane, pc);
+            pf.aux[i][pc] = (m < M && ncol) ? *(const bf16x8*)((const bf16*)p.aux + m * p.ldo + n)
+                                            : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
     }
+}
+
+template <int EPI>
+__device__ __forceinline__ void epilogue_prefetch(const EpiParams& p, EpiPrefetch<EPI>& pf, int64_t mtile, int64_t ntile, int64_t M,
+                                                  int64_t N, int lane) {
+    epilogue_prefetch_bias<EPI>(p, pf, ntile, N, lane);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) epilogue_prefetch_subtile<EPI>(p, pf, i, mtile, ntile, M, N, lane);
 }
 
 // one 16-row sub-tile i of the wave's slab: scratch (fp32 [16][SCRATCH_LD]) -> global
