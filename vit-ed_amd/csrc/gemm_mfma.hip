@@ -180,7 +180,8 @@ static void dispatch_nt(const bf16* a, int64_t lda, const bf16* b, int64_t ldb, 
     // tuning/diagnostic overrides: VITED_NT_BK = 32 | 64, VITED_NT_WM = 2 | 4
     static const int force_bk = getenv("VITED_NT_BK") ? atoi(getenv("VITED_NT_BK")) : 0;
     static const int force_wm = getenv("VITED_NT_WM") ? atoi(getenv("VITED_NT_WM")) : 0;
-    const bool shallow = force_bk ? force_bk == 32 : K <= 512;
+    // BK = 32 (4 workgroups / CU) pays only when the grid is large: at N = 384 (1,536 tiles) BK = 64 is 9-14 % faster
+    const bool shallow = force_bk ? force_bk == 32 : (K <= 512 && N >= 768);
     // measured (scratch/gemm_bench.py, M = 65536): the 256-row tile wins 5-10 % on plain-store K = 384 GEMMs with
     // N >= 768 (qkv, kv, fc1) and loses on the register-heavier epilogues, so it is used only there
     const bool tall = force_wm ? force_wm == 4 : (EPI == VITED_EPI_STORE && shallow && N >= 768 && M >= 8192);
