@@ -214,7 +214,11 @@ int gemm_nt_mfma(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t
 // fragments by an all-ones B operand (4 extra MFMAs per 32 rows, on one wave column), which leaves
 // sum_m dY[m, n] in every column of a 16 x 16 accumulator.
 // ================================================================================================
-#define TM 64
+#ifndef TN_TM
+#define TN_TM 64
+#endif
+#define TM TN_TM           // m-rows per stage: 64 (2 workgroups/CU) or 32 (3)
+#define TN_SLOTS (TM == 64 ? 512 : 768)
 #define T_TILE_BYTES (TM * 128 * 2)
 #define T_STAGE_BYTES (2 * T_TILE_BYTES)
 
@@ -229,8 +233,8 @@ __device__ __forceinline__ void tn_stage_load(const bf16* __restrict__ dY, int64
                                               int64_t kc0, int64_t K, char* stage, int wave, int lane) {
     const int rsub = lane >> 4, cp = lane & 15;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = wave * 16 + i * 4 + rsub;
+    for (int i = 0; i < TM / 16; ++i) {
+        const int r = wave * (TM / 4) + i * 4 + rsub;
         const int ch = cp ^ tn_f(r);
         int64_t gm = mrow0 + r;
         gm = gm <= mlast ? gm : mlast;  // clamped rows are zeroed in LDS after landing
@@ -238,8 +242,8 @@ __device__ __forceinline__ void tn_stage_load(const bf16* __restrict__ dY, int64
         cn = cn <= N - 8 ? cn : N - 8;
         int64_t ck = kc0 + ch * 8;
         ck = ck <= K - 8 ? ck : K - 8;
-        glds16(dY + gm * lddy + cn, stage + (wave * 16 + i * 4) * 256);
-        glds16(X + gm * ldx + ck, stage + T_TILE_BYTES + (wave * 16 + i * 4) * 256);
+        glds16(dY + gm * lddy + cn, stage + (wave * (TM / 4) + i * 4) * 256);
+        glds16(X + gm * ldx + ck, stage + T_TILE_BYTES + (wave * (TM / 4) + i * 4) * 256);
     }
 }
 
@@ -279,8 +283,8 @@ gemm_tn_mfma_kernel(const bf16* __restrict__ dY, int64_t lddy, const bf16* __res
         if (mrow0 + TM > me) {  // ragged last stage: zero the rows this lane's DMA clamped
             const int rsub = lane >> 4, cp = lane & 15;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = wave * 16 + i * 4 + rsub;
+            for (int i = 0; i < TM / 16; ++i) {
+                const int r = wave * (TM / 4) + i * 4 + rsub;
                 if (mrow0 + r >= me) {
                     *(f32x4*)(st + r * 256 + cp * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
                     *(f32x4*)(st + T_TILE_BYTES + r * 256 + cp * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -293,7 +297,7 @@ gemm_tn_mfma_kernel(const bf16* __restrict__ dY, int64_t lddy, const bf16* __res
         const char* sy = st;
         const char* sx = st + T_TILE_BYTES;
 #pragma unroll
-        for (int ms = 0; ms < 2; ++ms) {
+        for (int ms = 0; ms < TM / 32; ++ms) {
             bf16x8 af[4], bf_[4];
             const int r_lo = ms * 32 + 8 * g + q, r_hi = r_lo + 4;
             const int f_lo = tn_f(r_lo), f_hi = tn_f(r_hi);
@@ -368,7 +372,7 @@ bool gemm_tn_mfma_supported(const void* dY, int64_t lddy, const void* X, int64_t
 // in ONE round - one workgroup more than a round costs a whole extra round.
 int64_t gemm_tn_mfma_splits(int64_t M, int64_t N, int64_t K) {
     const int64_t tiles = ceil_div64(N, 128) * ceil_div64(K, 128);
-    int64_t s = 512 / tiles;
+    int64_t s = TN_SLOTS / tiles;
     const int64_t max_s = ceil_div64(M, 512);
     if (s > max_s) s = max_s;
     if (s < 1) s = 1;
