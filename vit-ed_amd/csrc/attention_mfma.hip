@@ -46,7 +46,9 @@ attn_fwd_small_kernel(AttnArgs a) {
         const bf16x8 z[C::KCH] = {};
         stage_tile<HD>(vs, 16 * NKT, 0, fr, g, z);
     }
-    __syncthreads();
+    // no barrier: the V image is wave-private and DS operations of one wave execute in order (the empty asm only
+    // stops the COMPILER from moving the transposed reads above the staging stores)
+    asm volatile("" ::: "memory");
     const float sc = a.scale * LOG2E;
     const int nqt = (nq + 15) >> 4;
     for (int i = 0; i < nqt; ++i) {
@@ -104,13 +106,20 @@ attn_fwd_small_kernel(AttnArgs a) {
 //   phase N (per key tile t; queries on accumulator rows, keys on lanes):
 //       S = Q K_t^T, dP = dO V_t^T -> dV_t^T = dO^T P (tr-read dO), dK_t^T = Q^T dS (tr-read Q)
 // ------------------------------------------------------------------------------------------------
+template <int HD, int NQT, int NKT> struct BwdSmallLds {
+    static constexpr int MAXT = NQT > NKT ? NQT : NKT;
+    static constexpr int IMG_TILES = (MAXT + 1) & ~1;                 // an odd count gets a zero phantom tile
+    static constexpr int IMG_BYTES = IMG_TILES * 16 * HD * 2;
+    static constexpr int STAT_FLOATS = IMG_TILES * 16;
+    static constexpr int WAVE_BYTES = 2 * IMG_BYTES + 2 * STAT_FLOATS * 4;
+};
+
 template <int HD, int NQT, int NKT>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256)   // 136-164 VGPRs: 3 workgroups per CU (forcing 4 spills and gains 3 % at best)
 attn_bwd_small_kernel(AttnArgs a) {
     using C = SmallCfg<HD>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int STAT_BYTES = (SM_MAX_TILES + 1) * 16 * 4;
-    constexpr int WAVE_BYTES = 3 * C::TILE_BYTES + 2 * STAT_BYTES;
+    using L = BwdSmallLds<HD, NQT, NKT>;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int fr = lane & 15, g = lane >> 4, qq = fr >> 2, p = fr & 3;
@@ -125,11 +134,14 @@ attn_bwd_small_kernel(AttnArgs a) {
     const bf16* vb = (const bf16*)a.v + b * a.v_bs + hoff;
     const bf16* ob = (const bf16*)a.o + b * a.o_bs + hoff;
     const bf16* dob = (const bf16*)a.d_o + b * a.o_bs + hoff;
-    char* k_s = smem + wave * WAVE_BYTES;
-    char* q_s = k_s + C::TILE_BYTES;
-    char* do_s = q_s + C::TILE_BYTES;
-    float* lse_s = (float*)(do_s + C::TILE_BYTES);
-    float* del_s = lse_s + (SM_MAX_TILES + 1) * 16;
+    // wave-private LDS: image slot 0 holds K during phase T and Q during phase N, slot 1 holds dO.  Two slots
+    // instead of three is what lets a third workgroup fit on a CU; everything is written and read by the same
+    // wave (DS operations of one wave execute in order), so no workgroup barrier is needed anywhere.
+    char* k_s = smem + wave * L::WAVE_BYTES;
+    char* q_s = k_s;
+    char* do_s = k_s + L::IMG_BYTES;
+    float* lse_s = (float*)(do_s + L::IMG_BYTES);
+    float* del_s = lse_s + L::STAT_FLOATS;
     const float sc = a.scale * LOG2E;
 
     bf16x8 kf[NKT][C::KCH], vf[NKT][C::KCH], qf[NQT][C::KCH], dof[NQT][C::KCH];
@@ -143,7 +155,6 @@ attn_bwd_small_kernel(AttnArgs a) {
     for (int i = 0; i < NQT; ++i) {
         load_row_frags<HD>(qb, a.q_ts, 16 * i, nq, fr, g, qf[i]);
         load_row_frags<HD>(dob, a.o_ts, 16 * i, nq, fr, g, dof[i]);
-        stage_tile<HD>(q_s, 16 * i, nq, fr, g, qf[i]);
         stage_tile<HD>(do_s, 16 * i, nq, fr, g, dof[i]);
         // delta[q] = sum_d O[q][d] dO[q][d]; lse in log2 units
         bf16x8 of[C::KCH];
@@ -163,12 +174,9 @@ attn_bwd_small_kernel(AttnArgs a) {
     {
         const bf16x8 z[C::KCH] = {};
         if (NKT & 1) stage_tile<HD>(k_s, 16 * NKT, 0, fr, g, z);
-        if (NQT & 1) {
-            stage_tile<HD>(q_s, 16 * NQT, 0, fr, g, z);
-            stage_tile<HD>(do_s, 16 * NQT, 0, fr, g, z);
-        }
+        if (NQT & 1) stage_tile<HD>(do_s, 16 * NQT, 0, fr, g, z);
     }
-    __syncthreads();
+    asm volatile("" ::: "memory");   // compiler-only fence (see the forward kernel)
 
     // ---- phase T: dQ -------------------------------------------------------------------------------
 #pragma unroll
@@ -206,6 +214,14 @@ attn_bwd_small_kernel(AttnArgs a) {
     }
 
     // ---- phase N: dK, dV ---------------------------------------------------------------------------
+    asm volatile("" ::: "memory");   // every transposed read of the K image is issued before slot 0 is overwritten
+#pragma unroll
+    for (int i = 0; i < NQT; ++i) stage_tile<HD>(q_s, 16 * i, nq, fr, g, qf[i]);   // slot 0: K image -> Q image
+    if (NQT & 1) {
+        const bf16x8 z[C::KCH] = {};
+        stage_tile<HD>(q_s, 16 * NQT, 0, fr, g, z);
+    }
+    asm volatile("" ::: "memory");
 #pragma unroll
     for (int t = 0; t < NKT; ++t) {
         f32x4 pr[NQT + 1], ds[NQT + 1];
@@ -293,11 +309,17 @@ int attention_fwd_mfma(const AttnArgs& a, hipStream_t s) {
     return VITED_ERR_UNSUPPORTED;
 }
 
+template <int NQT, int NKT>
+static void launch_bwd_small_one(const AttnArgs& a, dim3 grid, hipStream_t s) {
+    auto kernel = attn_bwd_small_kernel<32, NQT, NKT>;
+    constexpr size_t lds = 4 * BwdSmallLds<32, NQT, NKT>::WAVE_BYTES;
+    hipLaunchKernelGGL(kernel, grid, dim3(256), lds, s, a);
+}
+
 template <int NQT>
 static int launch_bwd_small32(const AttnArgs& a, int nkt, hipStream_t s) {
     dim3 grid((unsigned)a.batch, (unsigned)((a.heads + 3) / 4));
-    const size_t lds = 4 * (3 * SmallCfg<32>::TILE_BYTES + 2 * (SM_MAX_TILES + 1) * 16 * 4);
-#define L(N) hipLaunchKernelGGL((attn_bwd_small_kernel<32, NQT, N>), grid, dim3(256), lds, s, a)
+#define L(N) launch_bwd_small_one<NQT, N>(a, grid, s)
     switch (nkt) {
         case 1: L(1); break;
         case 2: L(2); break;
