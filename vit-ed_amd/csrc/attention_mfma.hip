@@ -34,7 +34,8 @@ attn_fwd_small_kernel(AttnArgs a) {
     const bf16* vb = (const bf16*)a.v + b * a.v_bs + (int64_t)h * HD;
     char* vs = smem + wave * C::TILE_BYTES;
 
-    bf16x8 kf[NKT][C::KCH];
+    bf16x8 kf[NKT][C::KCH], qnext[C::KCH];
+    load_row_frags<HD>(qb, a.q_ts, 0, nq, fr, g, qnext);   // query tiles are prefetched one iteration ahead
 #pragma unroll
     for (int t = 0; t < NKT; ++t) {
         load_row_frags<HD>(kb, a.k_ts, 16 * t, nk, fr, g, kf[t]);
@@ -53,7 +54,9 @@ attn_fwd_small_kernel(AttnArgs a) {
     const int nqt = (nq + 15) >> 4;
     for (int i = 0; i < nqt; ++i) {
         bf16x8 qf[C::KCH];
-        load_row_frags<HD>(qb, a.q_ts, 16 * i, nq, fr, g, qf);
+#pragma unroll
+        for (int c = 0; c < C::KCH; ++c) qf[c] = qnext[c];
+        if (i + 1 < nqt) load_row_frags<HD>(qb, a.q_ts, 16 * (i + 1), nq, fr, g, qnext);
         f32x4 st[NKT + 1];
         float m = -INFINITY;
 #pragma unroll
@@ -144,31 +147,40 @@ attn_bwd_small_kernel(AttnArgs a) {
     float* del_s = lse_s + L::STAT_FLOATS;
     const float sc = a.scale * LOG2E;
 
-    bf16x8 kf[NKT][C::KCH], vf[NKT][C::KCH], qf[NQT][C::KCH], dof[NQT][C::KCH];
+    // every global load of the (batch, head) item is issued before the first use: one exposed memory latency per
+    // wave instead of one per query tile (the staging / delta code below used to sit between the loads)
+    bf16x8 kf[NKT][C::KCH], vf[NKT][C::KCH], qf[NQT][C::KCH], dof[NQT][C::KCH], of[NQT][C::KCH];
+    float lse_r[NQT];
 #pragma unroll
     for (int t = 0; t < NKT; ++t) {
         load_row_frags<HD>(kb, a.k_ts, 16 * t, nk, fr, g, kf[t]);
         load_row_frags<HD>(vb, a.v_ts, 16 * t, nk, fr, g, vf[t]);
-        stage_tile<HD>(k_s, 16 * t, nk, fr, g, kf[t]);
     }
 #pragma unroll
     for (int i = 0; i < NQT; ++i) {
         load_row_frags<HD>(qb, a.q_ts, 16 * i, nq, fr, g, qf[i]);
         load_row_frags<HD>(dob, a.o_ts, 16 * i, nq, fr, g, dof[i]);
+        load_row_frags<HD>(ob, a.o_ts, 16 * i, nq, fr, g, of[i]);
+        const int q = 16 * i + fr;
+        lse_r[i] = a.lse[(b * a.heads + h) * a.nq + (q < nq ? q : nq - 1)];
+    }
+    asm volatile("" ::: "memory");   // keep the staging stores below the loads
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) stage_tile<HD>(k_s, 16 * t, nk, fr, g, kf[t]);
+#pragma unroll
+    for (int i = 0; i < NQT; ++i) {
         stage_tile<HD>(do_s, 16 * i, nq, fr, g, dof[i]);
         // delta[q] = sum_d O[q][d] dO[q][d]; lse in log2 units
-        bf16x8 of[C::KCH];
-        load_row_frags<HD>(ob, a.o_ts, 16 * i, nq, fr, g, of);
         float dl = 0.f;
 #pragma unroll
         for (int c = 0; c < C::KCH; ++c)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) dl = fmaf((float)of[c][e], (float)dof[i][c][e], dl);
+            for (int e = 0; e < 8; ++e) dl = fmaf((float)of[i][c][e], (float)dof[i][c][e], dl);
         dl = group_sum4(dl);
         const int q = 16 * i + fr;
         if (g == 0) {
             del_s[q] = dl;
-            lse_s[q] = a.lse[(b * a.heads + h) * a.nq + (q < nq ? q : nq - 1)] * LOG2E;
+            lse_s[q] = lse_r[i] * LOG2E;
         }
     }
     {
