@@ -145,9 +145,10 @@ gemm_nt_mfma_kernel(const bf16* __restrict__ A, int64_t lda, const bf16* __restr
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int e = 0; e < 4; ++e) sc[(fq * 4 + e) * SCRATCH_LD + j * 16 + fr] = acc[i][j][e];
-        __syncthreads();
+        // the scratch is wave-private and a wave's DS operations execute in order: only the compiler needs a fence
+        asm volatile("" ::: "memory");
         epilogue_subtile<EPI>(ep, pf, sc, i, mtile, ntile, M, N, lane);
-        __syncthreads();
+        asm volatile("" ::: "memory");
     }
 }
 
