@@ -220,6 +220,9 @@ int gemm_nt_mfma(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t
 #endif
 #define TM TN_TM           // m-rows per stage: 64 (2 workgroups/CU) or 32 (3)
 #define TN_SLOTS (TM == 64 ? 512 : 768)
+#ifndef TN_STAGES
+#define TN_STAGES 2
+#endif
 #define T_TILE_BYTES (TM * 128 * 2)
 #define T_STAGE_BYTES (2 * T_TILE_BYTES)
 
@@ -276,10 +279,20 @@ gemm_tn_mfma_kernel(const bf16* __restrict__ dY, int64_t lddy, const bf16* __res
 
     const int nsteps = me > mb ? (int)((me - mb + TM - 1) / TM) : 0;
     if (nsteps > 0) tn_stage_load(dY, lddy, X, ldx, mb, me - 1, n0, N, kc0, K, smem, wave, lane);
+#if TN_STAGES == 3
+    if (nsteps > 1) tn_stage_load(dY, lddy, X, ldx, mb + TM, me - 1, n0, N, kc0, K, smem + T_STAGE_BYTES, wave, lane);
+#endif
     const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
     for (int t = 0; t < nsteps; ++t) {
+#if TN_STAGES == 3
+        // three-slot ring: stage t + 1 stays in flight across the barrier (counted vmcnt, raw s_barrier)
+        if (t + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (TM / 16)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        char* st = smem + (t % 3) * T_STAGE_BYTES;
+#else
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         char* st = smem + (t & 1) * T_STAGE_BYTES;
+#endif
         const int64_t mrow0 = mb + (int64_t)t * TM;
         if (mrow0 + TM > me) {  // ragged last stage: zero the rows this lane's DMA clamped
             const int rsub = lane >> 4, cp = lane & 15;
@@ -292,11 +305,22 @@ gemm_tn_mfma_kernel(const bf16* __restrict__ dY, int64_t lddy, const bf16* __res
                 }
             }
         }
+#if TN_STAGES == 3
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // stage t landed for every wave; everyone is done reading stage t - 1
+        asm volatile("" ::: "memory");
+        if (t + 2 < nsteps)
+            tn_stage_load(dY, lddy, X, ldx, mrow0 + 2 * TM, me - 1, n0, N, kc0, K, smem + ((t + 2) % 3) * T_STAGE_BYTES, wave, lane);
+#else
         __syncthreads();
         if (t + 1 < nsteps)
             tn_stage_load(dY, lddy, X, ldx, mrow0 + TM, me - 1, n0, N, kc0, K, smem + ((t + 1) & 1) * T_STAGE_BYTES, wave, lane);
+#endif
         const char* sy = st;
         const char* sx = st + T_TILE_BYTES;
+#ifdef TN_DBG_DMA_ONLY
+        continue;
+#endif
 #pragma unroll
         for (int ms = 0; ms < TM / 32; ++ms) {
             bf16x8 af[4], bf_[4];
@@ -319,8 +343,13 @@ gemm_tn_mfma_kernel(const bf16* __restrict__ dY, int64_t lddy, const bf16* __res
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < 4; ++j) {
+#ifdef TN_DBG_NO_MFMA
+                    asm volatile("" ::"v"(af[i]), "v"(bf_[j]));
+#else
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf_[j], acc[i][j], 0, 0, 0);
+#endif
+                }
             if (BIAS && kc0 == 0) {
                 // column sums of dY on the VALU (v_dot2_f32_bf16 against packed ones), branch-free so the MFMA
                 // schedule is untouched: an MFMA-by-ones variant and a dealt (conditional) one both cost 70-100 VGPRs
@@ -387,10 +416,10 @@ int gemm_tn_mfma(const void* dY, int64_t lddy, const void* X, int64_t ldx, int64
     const int tiles = (int)ceil_div64(N, 128) * tiles_k;
     const int64_t rps = ceil_div64(ceil_div64(M, splits), TM) * TM;
     if (bias_out)
-        hipLaunchKernelGGL((gemm_tn_mfma_kernel<true>), dim3(tiles, (unsigned)splits), dim3(256), 2 * T_STAGE_BYTES, s,
+        hipLaunchKernelGGL((gemm_tn_mfma_kernel<true>), dim3(tiles, (unsigned)splits), dim3(256), TN_STAGES * T_STAGE_BYTES, s,
                            (const bf16*)dY, lddy, (const bf16*)X, ldx, M, N, K, rps, tiles_k, out, bias_out);
     else
-        hipLaunchKernelGGL((gemm_tn_mfma_kernel<false>), dim3(tiles, (unsigned)splits), dim3(256), 2 * T_STAGE_BYTES, s,
+        hipLaunchKernelGGL((gemm_tn_mfma_kernel<false>), dim3(tiles, (unsigned)splits), dim3(256), TN_STAGES * T_STAGE_BYTES, s,
                            (const bf16*)dY, lddy, (const bf16*)X, ldx, M, N, K, rps, tiles_k, out, bias_out);
     return vited_check_launch();
 }
