@@ -26,14 +26,15 @@
 namespace as {
 
 constexpr int NKS = 6;                 // K = 384 = 6 slices of 64
-#ifndef AS_NSLOT
-#define AS_NSLOT 16
-#endif
-#ifndef AS_DIST
-#define AS_DIST 7
-#endif
-constexpr int NSLOT = AS_NSLOT, DIST = AS_DIST;   // ring slots / slices in flight ahead of the consumer
-static_assert(DIST >= 2 && DIST <= NKS + 1 && NSLOT >= DIST + 2, "ring geometry");
+// RW = 16-row sub-tiles per wave.  RW = 4: 256-row workgroup, whole register file, 1 workgroup per CU (the first
+// version).  RW = 2: 128-row workgroup, <= 256 VGPRs, 2 workgroups per CU - one workgroup's stores and stream
+// hiccups hide under the other's MFMAs, at the price of streaming W once per 128 instead of 256 rows.
+template <int RW> struct Geo {
+    static constexpr int NSLOT = RW == 4 ? 16 : 8;   // ring slots
+    static constexpr int DIST = RW == 4 ? 7 : 5;     // slices in flight ahead of the consumer
+    static constexpr int ROWS = 64 * RW;             // rows per workgroup
+    static_assert(DIST >= 2 && DIST <= NKS + 1 && NSLOT >= DIST + 2, "ring geometry");
+};
 constexpr int BN = 64;                 // unit width (columns)
 constexpr int SLICE_BYTES = BN * 64 * 2;
 constexpr int MAX_N = 2048;            // bias staged in LDS
@@ -54,6 +55,7 @@ struct WStream {
     int64_t tile_stride;  // BN * ldw elements
     int j, k, slot;       // next slice to issue: n-tile, k-slice, ring slot
 };
+template <int NSLOT>
 __device__ __forceinline__ void issue_next_slice(WStream& ws, char* ring, int tiles_n, int wave) {
     const int64_t o = (int64_t)ws.j * ws.tile_stride + ws.k * 64;
     char* dst = ring + ws.slot * SLICE_BYTES + wave * 16 * 128;
@@ -63,18 +65,19 @@ __device__ __forceinline__ void issue_next_slice(WStream& ws, char* ring, int ti
     if (++ws.slot == NSLOT) ws.slot = 0;
 }
 
-struct AFrags {
-    bf16x8 f[NKS][2][4];  // [k slice][kk][16-row sub-tile]
+template <int RW> struct AFrags {
+    bf16x8 f[NKS][2][RW];  // [k slice][kk][16-row sub-tile]
 };
 struct WFrags {
     bf16x8 f[4];          // one half-slice (32 k): 4 n-tiles of 16
 };
 
-__device__ __forceinline__ void load_a(const bf16* __restrict__ A, int64_t lda, int64_t row0, int fr, int fq, int ks, AFrags& a) {
+template <int RW>
+__device__ __forceinline__ void load_a(const bf16* __restrict__ A, int64_t lda, int64_t row0, int fr, int fq, int ks, AFrags<RW>& a) {
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a.f[ks][kk][i] = *(const bf16x8*)(A + (row0 + i * 16 + fr) * lda + ks * 64 + kk * 32 + fq * 8);
+        for (int i = 0; i < RW; ++i) a.f[ks][kk][i] = *(const bf16x8*)(A + (row0 + i * 16 + fr) * lda + ks * 64 + kk * 32 + fq * 8);
 }
 
 __device__ __forceinline__ void read_w(const char* slice, int kk, int fr, int fq, WFrags& w) {
@@ -83,20 +86,21 @@ __device__ __forceinline__ void read_w(const char* slice, int kk, int fr, int fq
 }
 
 // D[n_local = 4 fq + e][m_local = fr] += W_frag . A_frag^T  (transposed product, see header)
-__device__ __forceinline__ void mma_half(f32x4 (&acc)[4][4], const WFrags& w, const bf16x8 (&af)[4]) {
+template <int RW>
+__device__ __forceinline__ void mma_half(f32x4 (&acc)[RW][4], const WFrags& w, const bf16x8 (&af)[RW]) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
 #ifdef AS_DBG_NO_MFMA
         asm volatile("" ::"v"(w.f[j]));
 #else
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.f[j], af[i], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < RW; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.f[j], af[i], acc[i][j], 0, 0, 0);
 #endif
     }
 }
 
-template <int EPI> struct OutTraits {
-    static constexpr int NST = 16 * (EPI == VITED_EPI_GELU ? 2 : 1);  // store instructions per wave and unit
+template <int EPI, int RW> struct OutTraits {
+    static constexpr int NST = 4 * RW * (EPI == VITED_EPI_GELU ? 2 : 1);  // store instructions per wave and unit
 };
 
 // lane (fr, fq) holds out[m = mrow0 + 16 i + fr][n = n0 + 16 j + 4 fq + (0..3)] in acc[i][j] (bias already
@@ -110,12 +114,12 @@ struct OutDesc {
     int ldo_bytes;  // row pitch in bytes
 };
 
-template <int EPI>
-__device__ __forceinline__ void epilogue_unit(const OutDesc& od, const f32x4 (&acc)[4][4], int64_t mrow0, int64_t n0) {
+template <int EPI, int RW>
+__device__ __forceinline__ void epilogue_unit(const OutDesc& od, const f32x4 (&acc)[RW][4], int64_t mrow0, int64_t n0) {
     constexpr int ES = EPI == VITED_EPI_STORE_F32 ? 4 : 2;
     const int base = __builtin_amdgcn_readfirstlane((int)(mrow0 * od.ldo_bytes + n0 * ES));
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < RW; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int soff = base + i * 16 * od.ldo_bytes + j * 16 * ES;
@@ -136,57 +140,59 @@ __device__ __forceinline__ void epilogue_unit(const OutDesc& od, const f32x4 (&a
 // One (m-tile, n-tile) unit = 6 ring slices.  On entry F0 holds the operand fragments of (slice s, kk 0).
 // RELOAD: the next unit starts a new m-tile, so each A slice is re-fetched for it as soon as its last
 // use here has issued.
-template <int EPI, bool RELOAD>
+template <int EPI, int RW, bool RELOAD>
 __device__ __forceinline__ void run_unit(const bf16* __restrict__ A, int64_t lda, const bf16* __restrict__ W, int64_t ldw, char* ring,
-                                         const float* bias_lds, const OutDesc& od, AFrags& a, WFrags& F0, WFrags& F1, int& s, int s_end,
+                                         const float* bias_lds, const OutDesc& od, AFrags<RW>& a, WFrags& F0, WFrags& F1, int& s, int s_end,
                                          WStream& ws, int& cur_slot, int tiles_n, bool first_unit, int64_t mrow0, int64_t next_mrow0,
                                          int64_t n0, int wave, int lane) {
+    constexpr int NSLOT = Geo<RW>::NSLOT, DIST = Geo<RW>::DIST;
     const int fr = lane & 15, fq = lane >> 4;
-    f32x4 acc[4][4];   // start from the bias of this lane's 4 columns (zeros were staged when there is none)
+    f32x4 acc[RW][4];   // start from the bias of this lane's 4 columns (zeros were staged when there is none)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const f32x4 b = *(const f32x4*)(bias_lds + n0 + 16 * j + 4 * fq);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i][j] = b;
+        for (int i = 0; i < RW; ++i) acc[i][j] = b;
     }
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks, ++s) {
         const char* cur = ring + cur_slot * SLICE_BYTES;
         read_w(cur, 1, fr, fq, F1);                       // second half of slice s, one phase ahead
-        mma_half(acc, F0, a.f[ks][0]);                    // first half (fragments read one phase ago)
+        mma_half<RW>(acc, F0, a.f[ks][0]);                    // first half (fragments read one phase ago)
         if (s + 1 < s_end) {
             // Slice s+1 has landed once only VMEM ops issued after its 2 DMAs may be outstanding: the DMAs
             // of slices s+2 .. s+DIST-1 (2 each) and, when the previous unit's epilogue was issued inside
             // that window (ks <= DIST-2), its NST stores.  A reloads only add younger ops (safe side).
             constexpr int AHEAD = 2 * (DIST - 2);
-            constexpr int WITH_ST = AHEAD + OutTraits<EPI>::NST > 63 ? 63 : AHEAD + OutTraits<EPI>::NST;  // 6-bit counter
+            constexpr int WITH_ST = AHEAD + OutTraits<EPI, RW>::NST > 63 ? 63 : AHEAD + OutTraits<EPI, RW>::NST;  // 6-bit counter
             if (s + DIST - 1 < s_end) {
                 if (!first_unit && ks <= DIST - 2) wait_vmcnt<WITH_ST>(); else wait_vmcnt<AHEAD>();
             } else {
                 wait_vmcnt<0>();                          // tail of the stream
             }
             block_barrier();   // slice s+1 complete in LDS for every wave; slot of slice s+DIST-NSLOT is free
-            if (s + DIST < s_end) issue_next_slice(ws, ring, tiles_n, wave);
+            if (s + DIST < s_end) issue_next_slice<NSLOT>(ws, ring, tiles_n, wave);
             if (++cur_slot == NSLOT) cur_slot = 0;
             read_w(ring + cur_slot * SLICE_BYTES, 0, fr, fq, F0);            // first half of slice s+1
         }
-        mma_half(acc, F1, a.f[ks][1]);
-        if constexpr (RELOAD) load_a(A, lda, next_mrow0, fr, fq, ks, a);
+        mma_half<RW>(acc, F1, a.f[ks][1]);
+        if constexpr (RELOAD) load_a<RW>(A, lda, next_mrow0, fr, fq, ks, a);
     }
 #ifdef AS_DBG_NO_EPI
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < RW; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
     return;
 #endif
-    epilogue_unit<EPI>(od, acc, mrow0, n0);
+    epilogue_unit<EPI, RW>(od, acc, mrow0, n0);
 }
 
-template <int EPI>
-__global__ void __launch_bounds__(256, 1)
+template <int EPI, int RW>
+__global__ void __launch_bounds__(256, RW == 4 ? 1 : 2)
 gemm_nt_as_kernel(const bf16* __restrict__ A, int64_t lda, const bf16* __restrict__ W, int64_t ldw, int64_t N, int tiles_m,
                   int tiles_n, EpiParams ep) {
+    constexpr int NSLOT = Geo<RW>::NSLOT, DIST = Geo<RW>::DIST, ROWS = Geo<RW>::ROWS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ring = smem;
     float* bias_lds = (float*)(smem + NSLOT * SLICE_BYTES);
@@ -204,17 +210,17 @@ gemm_nt_as_kernel(const bf16* __restrict__ A, int64_t lda, const bf16* __restric
     OutDesc od;
     {
         constexpr int ES = EPI == VITED_EPI_STORE_F32 ? 4 : 2;
-        const int64_t bytes = (int64_t)tiles_m * 256 * ep.ldo * ES;
+        const int64_t bytes = (int64_t)tiles_m * ROWS * ep.ldo * ES;
         od.out = __builtin_amdgcn_make_buffer_rsrc(ep.out, 0, (int)bytes, 0x00020000);
         od.out2 = __builtin_amdgcn_make_buffer_rsrc(EPI == VITED_EPI_GELU ? ep.out2 : ep.out, 0, (int)bytes, 0x00020000);
         od.lane_off = (int)((fr * ep.ldo + 4 * fq) * ES);
         od.ldo_bytes = (int)(ep.ldo * ES);
     }
-    AFrags a;
+    AFrags<RW> a;
     {
-        const int64_t mrow0 = (u0 / tiles_n) * 256 + wave * 64;
+        const int64_t mrow0 = (u0 / tiles_n) * ROWS + wave * 16 * RW;
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) load_a(A, lda, mrow0, fr, fq, ks, a);
+        for (int ks = 0; ks < NKS; ++ks) load_a<RW>(A, lda, mrow0, fr, fq, ks, a);
     }
     WStream ws;
     {
@@ -232,7 +238,7 @@ gemm_nt_as_kernel(const bf16* __restrict__ A, int64_t lda, const bf16* __restric
     // fill the ring: slices 0 .. DIST-1
 #pragma unroll
     for (int d = 0; d < DIST; ++d)
-        if (d < s_end) issue_next_slice(ws, ring, tiles_n, wave);
+        if (d < s_end) issue_next_slice<NSLOT>(ws, ring, tiles_n, wave);
     int cur_slot = 0;
     __syncthreads();   // bias copy + first slices visible (this waits for everything issued so far)
     WFrags F0, F1;
@@ -242,12 +248,12 @@ gemm_nt_as_kernel(const bf16* __restrict__ A, int64_t lda, const bf16* __restric
     int j = u0_j;
     for (int iu = 0; iu < n_units; ++iu, ++j) {
         if (j == tiles_n) { j = 0; ++mt; }
-        const int64_t mrow0 = mt * 256 + wave * 64;
+        const int64_t mrow0 = mt * ROWS + wave * 16 * RW;
         const bool reload = (j == tiles_n - 1) && (iu + 1 < n_units);
         if (reload)
-            run_unit<EPI, true>(A, lda, W, ldw, ring, bias_lds, od, a, F0, F1, s, s_end, ws, cur_slot, tiles_n, iu == 0, mrow0, mrow0 + 256, (int64_t)j * BN, wave, lane);
+            run_unit<EPI, RW, true>(A, lda, W, ldw, ring, bias_lds, od, a, F0, F1, s, s_end, ws, cur_slot, tiles_n, iu == 0, mrow0, mrow0 + ROWS, (int64_t)j * BN, wave, lane);
         else
-            run_unit<EPI, false>(A, lda, W, ldw, ring, bias_lds, od, a, F0, F1, s, s_end, ws, cur_slot, tiles_n, iu == 0, mrow0, 0, (int64_t)j * BN, wave, lane);
+            run_unit<EPI, RW, false>(A, lda, W, ldw, ring, bias_lds, od, a, F0, F1, s, s_end, ws, cur_slot, tiles_n, iu == 0, mrow0, 0, (int64_t)j * BN, wave, lane);
     }
 }
 
@@ -268,25 +274,35 @@ bool gemm_nt_as_supported(const void* A, int64_t lda, const void* B, int64_t ldb
                           const EpiParams& ep) {
     if (epilogue != VITED_EPI_STORE && epilogue != VITED_EPI_GELU && epilogue != VITED_EPI_STORE_F32) return false;
     if (!gemm_nt_mfma_supported(A, lda, B, ldb, M, N, K, epilogue, ep)) return false;
-    if (K != 64 * as::NKS || M % 256 || N % as::BN || N > as::MAX_N) return false;
-    if (M / 256 > (1 << 22)) return false;
+    if (K != 64 * as::NKS || M % 128 || N % as::BN || N > as::MAX_N) return false;
+    if (M / 128 > (1 << 22)) return false;
     if (M * ep.ldo * 4 >= (int64_t)1 << 31) return false;   // 32-bit buffer offsets
     return true;
 }
 
-template <int EPI>
-static int launch_as(const bf16* a, int64_t lda, const bf16* b, int64_t ldb, int64_t M, int64_t N, const EpiParams& ep, hipStream_t s) {
-    const int tiles_m = (int)(M / 256), tiles_n = (int)(N / as::BN);
-    int64_t grid = as_cu_count();
+template <int EPI, int RW>
+static int launch_as_rw(const bf16* a, int64_t lda, const bf16* b, int64_t ldb, int64_t M, int64_t N, const EpiParams& ep, hipStream_t s) {
+    using G = as::Geo<RW>;
+    const int tiles_m = (int)(M / G::ROWS), tiles_n = (int)(N / as::BN);
+    int64_t grid = (int64_t)as_cu_count() * (RW == 4 ? 1 : 2);
     if (grid > (int64_t)tiles_m * tiles_n) grid = (int64_t)tiles_m * tiles_n;
-    const size_t lds = (size_t)as::NSLOT * as::SLICE_BYTES + as::MAX_N * sizeof(float);
+    const size_t lds = (size_t)G::NSLOT * as::SLICE_BYTES + as::MAX_N * sizeof(float);
+    auto kernel = as::gemm_nt_as_kernel<EPI, RW>;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)as::gemm_nt_as_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL((as::gemm_nt_as_kernel<EPI>), dim3((unsigned)grid), dim3(256), lds, s, a, lda, b, ldb, N, tiles_m, tiles_n, ep);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(256), lds, s, a, lda, b, ldb, N, tiles_m, tiles_n, ep);
     return vited_check_launch();
+}
+
+template <int EPI>
+static int launch_as(const bf16* a, int64_t lda, const bf16* b, int64_t ldb, int64_t M, int64_t N, const EpiParams& ep, hipStream_t s) {
+    static const int force_rw = getenv("VITED_AS_RW") ? atoi(getenv("VITED_AS_RW")) : 0;   // tuning override: 2 | 4
+    const bool wide = force_rw ? force_rw == 4 : false;
+    if (wide && M % 256 == 0) return launch_as_rw<EPI, 4>(a, lda, b, ldb, M, N, ep, s);
+    return launch_as_rw<EPI, 2>(a, lda, b, ldb, M, N, ep, s);
 }
 
 int gemm_nt_as(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K, int epilogue,
