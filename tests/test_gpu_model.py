@@ -242,18 +242,21 @@ def test_pairwise_similarity_matches_one_shot_pairs(vited, gpu):
         model(model(imgs[:2], forward_first_part=True), imgs, x2_index=torch.tensor([0, 1], device=gpu))
 
 
+@pytest.mark.parametrize('shape', ['A2', 'one_class', 'T'])
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
-def test_direct_gradient_accumulation_matches_autograd(vited, gpu, dtype):
+def test_direct_gradient_accumulation_matches_autograd(vited, gpu, dtype, shape):
     """engine.FlatGradients mode: the weight-gradient / LayerNorm kernels add straight into p.grad (views of
     one flat buffer) instead of returning tensors for autograd to accumulate.  Same numbers, and a second
     backward accumulates (ACCUMULATION_STEPS > 1, misc/engine.py:202-231)."""
-    s = vo.ViTEDShape(depth=2, c_depth=2)
+    # 'one_class': the [1, 384] head of config H (odd widths in the slab reductions); 'T': the tiny test config
+    s = {'A2': vo.ViTEDShape(depth=2, c_depth=2), 'one_class': vo.ViTEDShape(depth=1, c_depth=1, num_classes=1),
+         'T': vo.SHAPE_T}[shape]
     torch.manual_seed(2)
     ref = _hip_model(vited, s, gpu, dtype)
     dut = _hip_model(vited, s, gpu, dtype)
     dut.load_state_dict(ref.state_dict())
-    x = torch.randn(6, 2, 3, 64, 64, device=gpu).clamp(-1, 1)
-    y = (torch.rand(6, 4, device=gpu) > 0.75).float()
+    x = torch.randn(6, 2, 3, s.img_size, s.img_size, device=gpu).clamp(-1, 1)
+    y = (torch.rand(6, s.num_classes, device=gpu) > 0.75).float()
     torch.nn.functional.binary_cross_entropy_with_logits(ref(x), y).backward()
     flat = vited.engine.FlatGradients(dut.parameters())
     dut.direct_param_grads = True

@@ -344,14 +344,22 @@ __global__ void sum_slabs_pair_kernel(const float* __restrict__ in_a, int64_t ld
 }
 
 
+// any width / alignment (e.g. the [1, 384] head of config H and its 1-element bias): one column per thread
+__global__ void sum_slabs_scalar_kernel(const float* __restrict__ in, int64_t in_ld, float* __restrict__ out, int64_t batch,
+                                        int64_t width, int accumulate) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= width) return;
+    float acc = accumulate ? out[c] : 0.f;
+    for (int64_t b = 0; b < batch; ++b) acc += in[b * in_ld + c];
+    out[c] = acc;
+}
+
 int sum_rows_f32_single_pass(const float* in, int64_t in_ld, float* out, int64_t batch, int64_t width, hipStream_t s, int accumulate) {
     const bool vec = (width % 4 == 0) && (in_ld % 4 == 0) && ((((uintptr_t)in) | ((uintptr_t)out)) & 15) == 0;
     if (vec)
         hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)ceil_div64(width, 1024)), dim3(256), 0, s, in, in_ld, out, batch, width, accumulate);
-    else if (!accumulate)
-        hipLaunchKernelGGL((sum_rows_kernel<float>), dim3((unsigned)ceil_div64(width, 256), 1), dim3(256), 0, s, in, in_ld, out, batch, width, batch);
     else
-        return VITED_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL(sum_slabs_scalar_kernel, dim3((unsigned)ceil_div64(width, 256)), dim3(256), 0, s, in, in_ld, out, batch, width, accumulate);
     return vited_check_launch();
 }
 
