@@ -16,6 +16,7 @@
 //                         delta; S = Q K^T and dP = dO V^T put the query on accumulator rows, so
 //                         dV^T += dO^T P and dK^T += Q^T dS contract over accumulator rows again.
 //             Both kernels accumulate in registers across the loop: no atomics, bit-reproducible.
+#include <type_traits>
 #include "attention_tiles.h"
 
 #define FL_TILE 64   // keys (or queries) per LDS tile
@@ -43,12 +44,13 @@ __device__ __forceinline__ void tile_to_regs(const bf16* base, int64_t ts, int r
 // ... and registers -> LDS image (rows >= n zeroed)
 template <int HD>
 __device__ __forceinline__ void regs_to_tile(char* lds, int row0, int n, int tid, const bf16x8 (&r)[FlashCfg<HD>::PASSES]) {
+    const bool ragged = row0 + FL_TILE > n;   // uniform: full tiles skip the per-row select
 #pragma unroll
     for (int c = 0; c < FlashCfg<HD>::PASSES; ++c) {
         const int idx = tid + 256 * c;
         const int row = idx / FlashCfg<HD>::CHUNKS_PER_ROW, ch = idx % FlashCfg<HD>::CHUNKS_PER_ROW;
         bf16x8 v = r[c];
-        if (row0 + row >= n) v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        if (ragged && row0 + row >= n) v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
         *(bf16x8*)(lds + SmallCfg<HD>::off(row, ch * 16)) = v;
     }
 }
@@ -109,47 +111,68 @@ attn_fwd_flash_kernel(AttnArgs a) {
         bf16x8 kf[4][C::KCH];
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) lds_row_frags<HD>(ks, kt, fr, g, kf[kt]);
+        // The loop is VALU-bound (softmax work per score > MFMA time per score at hd 64), so every VALU instruction
+        // counts: the key mask exists only in a ragged last tile, the scale rides in the exp2 argument's FMA, exp2 is
+        // the raw v_exp_f32 (a probability below 2^-126 is 0 either way) and O is rescaled only when some lane's
+        // running maximum moved.
+        auto tile_body = [&](auto ragged_tag) {
+        constexpr bool RAGGED = decltype(ragged_tag)::value;
+        f32x4 st[FL_W][4];
 #pragma unroll
         for (int w = 0; w < FL_W; ++w) {
-            f32x4 st[4];
             float tmax = -INFINITY;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
                 f32x4 s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int c = 0; c < C::KCH; ++c) s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt][c], qf[w][c], s, 0, 0, 0);
+                if constexpr (RAGGED) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    s[e] = (t * FL_TILE + 16 * kt + 4 * g + e) < nk ? s[e] * sc : -INFINITY;
-                    tmax = fmaxf(tmax, s[e]);
+                    for (int e = 0; e < 4; ++e) s[e] = (t * FL_TILE + 16 * kt + 4 * g + e) < nk ? s[e] : -INFINITY;
                 }
-                st[kt] = s;
+                tmax = fmaxf(fmaxf(tmax, fmaxf(s[0], s[1])), fmaxf(s[2], s[3]));
+                st[w][kt] = s;
             }
-            tmax = group_max4(tmax);
-            const float mn = fmaxf(m[w], tmax);
-            const float alpha = exp2f(m[w] - mn);
+            tmax = group_max4(tmax) * sc;          // sc > 0: the maximum commutes with the scale
+            // Lazy reference maximum: m[w] only moves when some query's tile maximum exceeds it by more than 2^8
+            // (probabilities then stay below 256 - exact in fp32 sums, harmless in bf16 operands); the softmax and the
+            // LSE are mathematically unchanged, and the O rescale (accumulator -> VGPR -> accumulator) becomes rare.
+            if (__any(tmax > m[w] + 8.f)) {
+                asm volatile("" ::: "memory");   // keep this a branch
+                const float mn = fmaxf(m[w], tmax);
+                const float alpha = __builtin_amdgcn_exp2f(m[w] - mn);
+                l[w] *= alpha;
+                m[w] = mn;
+#pragma unroll
+                for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[w][dt][e] *= alpha;
+            }
+            const float mref = m[w];
             float ls = 0.f;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float pe = exp2f(st[kt][e] - mn);
-                    st[kt][e] = pe;
+                    const float pe = __builtin_amdgcn_exp2f(fmaf(st[w][kt][e], sc, -mref));
+                    st[w][kt][e] = pe;
                     ls += pe;
                 }
-            l[w] = l[w] * alpha + group_sum4(ls);
-            m[w] = mn;
-#pragma unroll
-            for (int dt = 0; dt < C::DT; ++dt) {
-                f32x4 acc = o[w][dt];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[e] *= alpha;
-#pragma unroll
-                for (int k2 = 0; k2 < 2; ++k2)
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<HD>(vs, k2, dt, g, qq, p), pack_pair(st[2 * k2], st[2 * k2 + 1]), acc, 0, 0, 0);
-                o[w][dt] = acc;
-            }
+            l[w] += group_sum4(ls);
         }
+        // O^T += V^T P^T: each transposed V fragment is read once and feeds every query tile of the wave
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+                const bf16x8 vt = tr_frag<HD>(vs, k2, dt, g, qq, p);
+#pragma unroll
+                for (int w = 0; w < FL_W; ++w)
+                    o[w][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt, pack_pair(st[w][2 * k2], st[w][2 * k2 + 1]), o[w][dt], 0, 0, 0);
+            }
+        };
+        if ((t + 1) * FL_TILE > nk) tile_body(std::true_type{});   // one wave-uniform branch per tile
+        else tile_body(std::false_type{});
         if (t + 1 < ntiles) {
             char* nks = smem + ((t + 1) & 1) * 2 * F::TILE_BYTES;
             regs_to_tile<HD>(nks, (t + 1) * FL_TILE, nk, tid, kr);
@@ -176,7 +199,7 @@ attn_fwd_flash_kernel(AttnArgs a) {
 // backward 1/2: dQ (and delta)
 // ------------------------------------------------------------------------------------------------
 template <int HD>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)   // 2 waves per SIMD: <= 256 VGPRs
 attn_bwd_dq_flash_kernel(AttnArgs a) {
     using C = SmallCfg<HD>;
     using F = FlashCfg<HD>;
@@ -238,9 +261,11 @@ attn_bwd_dq_flash_kernel(AttnArgs a) {
             lds_row_frags<HD>(ks, kt, fr, g, kf[kt]);
             lds_row_frags<HD>(vs, kt, fr, g, vf[kt]);
         }
+        auto tile_body = [&](auto ragged_tag) {   // VALU-bound like the forward loop: same instruction diet
+        constexpr bool RAGGED = decltype(ragged_tag)::value;
+        f32x4 ds[FL_W][4];
 #pragma unroll
         for (int w = 0; w < FL_W; ++w) {
-            f32x4 ds[4];
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
                 f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
@@ -251,16 +276,24 @@ attn_bwd_dq_flash_kernel(AttnArgs a) {
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float pe = (t * FL_TILE + 16 * kt + 4 * g + e) < nk ? exp2f(s[e] * sc - lse2[w]) : 0.f;
-                    ds[kt][e] = pe * (dp[e] - dl[w]);
+                    float pe = __builtin_amdgcn_exp2f(fmaf(s[e], sc, -lse2[w]));
+                    if constexpr (RAGGED) pe = (t * FL_TILE + 16 * kt + 4 * g + e) < nk ? pe : 0.f;
+                    ds[w][kt][e] = pe * (dp[e] - dl[w]);
                 }
             }
-#pragma unroll
-            for (int dt = 0; dt < C::DT; ++dt)
-#pragma unroll
-                for (int k2 = 0; k2 < 2; ++k2)
-                    dq[w][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<HD>(ks, k2, dt, g, qq, p), pack_pair(ds[2 * k2], ds[2 * k2 + 1]), dq[w][dt], 0, 0, 0);
         }
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+                const bf16x8 kt_ = tr_frag<HD>(ks, k2, dt, g, qq, p);   // one transposed K fragment feeds every query tile
+#pragma unroll
+                for (int w = 0; w < FL_W; ++w)
+                    dq[w][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt_, pack_pair(ds[w][2 * k2], ds[w][2 * k2 + 1]), dq[w][dt], 0, 0, 0);
+            }
+        };
+        if ((t + 1) * FL_TILE > nk) tile_body(std::true_type{});
+        else tile_body(std::false_type{});
         if (t + 1 < ntiles) {
             char* nks = smem + ((t + 1) & 1) * 2 * F::TILE_BYTES;
             regs_to_tile<HD>(nks, (t + 1) * FL_TILE, nk, tid, kr);
@@ -285,7 +318,7 @@ attn_bwd_dq_flash_kernel(AttnArgs a) {
 // backward 2/2: dK, dV
 // ------------------------------------------------------------------------------------------------
 template <int HD>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)   // 2 waves per SIMD: <= 256 VGPRs
 attn_bwd_dkv_flash_kernel(AttnArgs a) {
     using C = SmallCfg<HD>;
     using F = FlashCfg<HD>;
@@ -349,37 +382,47 @@ attn_bwd_dkv_flash_kernel(AttnArgs a) {
             tile_to_regs<HD>(dob, a.o_ts, (t + 1) * FL_TILE, nq, tid, dor);
             load_stats(t + 1);
         }
+        auto tile_body = [&](auto ragged_tag) {   // VALU-bound: see the forward kernel
+        constexpr bool RAGGED = decltype(ragged_tag)::value;
+        f32x4 pr[FL_W][4], ds[FL_W][4];
 #pragma unroll
-        for (int w = 0; w < FL_W; ++w) {
-            f32x4 pr[4], ds[4];
+        for (int qt = 0; qt < 4; ++qt) {
+            bf16x8 qfr[C::KCH], dofr[C::KCH];   // one LDS read of the query-tile fragments serves every key tile of the wave
+            lds_row_frags<HD>(qs, qt, fr, g, qfr);
+            lds_row_frags<HD>(dos, qt, fr, g, dofr);
+            const f32x4 l4 = *(const f32x4*)(lse_s + 16 * qt + 4 * g);
+            const f32x4 d4 = *(const f32x4*)(del_s + 16 * qt + 4 * g);
 #pragma unroll
-            for (int qt = 0; qt < 4; ++qt) {
-                bf16x8 qfr[C::KCH], dofr[C::KCH];
-                lds_row_frags<HD>(qs, qt, fr, g, qfr);
-                lds_row_frags<HD>(dos, qt, fr, g, dofr);
+            for (int w = 0; w < FL_W; ++w) {
                 f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int c = 0; c < C::KCH; ++c) {
                     s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr[c], kf[w][c], s, 0, 0, 0);
                     dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dofr[c], vf[w][c], dp, 0, 0, 0);
                 }
-                const f32x4 l4 = *(const f32x4*)(lse_s + 16 * qt + 4 * g);
-                const f32x4 d4 = *(const f32x4*)(del_s + 16 * qt + 4 * g);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float pe = (t * FL_TILE + 16 * qt + 4 * g + e) < nq ? exp2f(s[e] * sc - l4[e]) : 0.f;
-                    pr[qt][e] = pe;
-                    ds[qt][e] = pe * (dp[e] - d4[e]);
+                    float pe = __builtin_amdgcn_exp2f(fmaf(s[e], sc, -l4[e]));
+                    if constexpr (RAGGED) pe = (t * FL_TILE + 16 * qt + 4 * g + e) < nq ? pe : 0.f;
+                    pr[w][qt][e] = pe;
+                    ds[w][qt][e] = pe * (dp[e] - d4[e]);
                 }
             }
-#pragma unroll
-            for (int dt = 0; dt < C::DT; ++dt)
-#pragma unroll
-                for (int q2 = 0; q2 < 2; ++q2) {
-                    dv[w][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<HD>(dos, q2, dt, g, qq, p), pack_pair(pr[2 * q2], pr[2 * q2 + 1]), dv[w][dt], 0, 0, 0);
-                    dk[w][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<HD>(qs, q2, dt, g, qq, p), pack_pair(ds[2 * q2], ds[2 * q2 + 1]), dk[w][dt], 0, 0, 0);
-                }
         }
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+            for (int q2 = 0; q2 < 2; ++q2) {
+                const bf16x8 dot_ = tr_frag<HD>(dos, q2, dt, g, qq, p), qt_ = tr_frag<HD>(qs, q2, dt, g, qq, p);
+#pragma unroll
+                for (int w = 0; w < FL_W; ++w) {
+                    dv[w][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot_, pack_pair(pr[w][2 * q2], pr[w][2 * q2 + 1]), dv[w][dt], 0, 0, 0);
+                    dk[w][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt_, pack_pair(ds[w][2 * q2], ds[w][2 * q2 + 1]), dk[w][dt], 0, 0, 0);
+                }
+            }
+        };
+        if ((t + 1) * FL_TILE > nq) tile_body(std::true_type{});
+        else tile_body(std::false_type{});
         if (t + 1 < ntiles) {
             char* nst = smem + ((t + 1) & 1) * STAGE_BYTES;
             regs_to_tile<HD>(nst, (t + 1) * FL_TILE, nq, tid, qr);
