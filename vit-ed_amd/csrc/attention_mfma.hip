@@ -64,21 +64,21 @@ attn_fwd_small_kernel(AttnArgs a) {
             f32x4 s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int c = 0; c < C::KCH; ++c) s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][c], qf[c], s, 0, 0, 0);
+            if (t == NKT - 1) {   // only the last key tile can be ragged (NKT = ceil(nk / 16))
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                s[e] = (16 * t + 4 * g + e) < nk ? s[e] * sc : -INFINITY;
-                m = fmaxf(m, s[e]);
+                for (int e = 0; e < 4; ++e) s[e] = (16 * t + 4 * g + e) < nk ? s[e] : -INFINITY;
             }
+            m = fmaxf(fmaxf(m, fmaxf(s[0], s[1])), fmaxf(s[2], s[3]));
             st[t] = s;
         }
         st[NKT] = f32x4{0.f, 0.f, 0.f, 0.f};
-        m = group_max4(m);
+        m = group_max4(m) * sc;   // sc > 0: the maximum commutes with the scale, which then rides in the exp2 FMA
         float l = 0.f;
 #pragma unroll
         for (int t = 0; t < NKT; ++t)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float pe = exp2f(st[t][e] - m);
+                const float pe = __builtin_amdgcn_exp2f(fmaf(st[t][e], sc, -m));   // raw v_exp_f32: p < 2^-126 is 0 either way
                 st[t][e] = pe;
                 l += pe;
             }
@@ -109,16 +109,34 @@ attn_fwd_small_kernel(AttnArgs a) {
 //   phase N (per key tile t; queries on accumulator rows, keys on lanes):
 //       S = Q K_t^T, dP = dO V_t^T -> dV_t^T = dO^T P (tr-read dO), dK_t^T = Q^T dS (tr-read Q)
 // ------------------------------------------------------------------------------------------------
+// Gradient tiles of the workgroup's 4 heads leave through a workgroup-shared LDS region laid out like the destination
+// rows ([row][4 heads x HD] bf16, 256 B per row at hd 32): one 16-byte store per lane covers 4 token rows x 256 B of full
+// cache lines.  (8-byte stores of 32-byte row pieces made the stores 55 % of this kernel; per-head 64-byte rows 45 %.)
+template <int HD, int NT>
+__device__ __forceinline__ void store_rows4(const char* region, bf16* dst_head0, int64_t ts, int n, int live_heads, int tid) {
+    constexpr int ROW = 4 * HD * 2, CPR = ROW / 16;   // bytes per staged row, 16-byte chunks per row
+#pragma unroll
+    for (int j = 0; j < NT * 16 * CPR / 256; ++j) {
+        const int c = tid + 256 * j;
+        const int row = c / CPR, ch = c % CPR;
+        const bf16x8 v = *(const bf16x8*)(region + row * ROW + ch * 16);
+        if (row < n && ch / (CPR / 4) < live_heads) *(bf16x8*)(dst_head0 + (int64_t)row * ts + ch * 8) = v;
+    }
+}
+
 template <int HD, int NQT, int NKT> struct BwdSmallLds {
     static constexpr int MAXT = NQT > NKT ? NQT : NKT;
     static constexpr int IMG_TILES = (MAXT + 1) & ~1;                 // an odd count gets a zero phantom tile
     static constexpr int IMG_BYTES = IMG_TILES * 16 * HD * 2;
     static constexpr int STAT_FLOATS = IMG_TILES * 16;
     static constexpr int WAVE_BYTES = 2 * IMG_BYTES + 2 * STAT_FLOATS * 4;
+    // workgroup layout: [slot 0 x 4 waves][slot 1 x 4 waves][stats x 4 waves]; the four slot-0 (or slot-1) images together
+    // are also the workgroup-shared staging region of store_rows4 (IMG_TILES * 4 KB >= NT * 16 rows * 256 B)
+    static constexpr int SLOT1_BASE = 4 * IMG_BYTES, STATS_BASE = 8 * IMG_BYTES;
 };
 
 template <int HD, int NQT, int NKT>
-__global__ void __launch_bounds__(256)   // 136-164 VGPRs: 3 workgroups per CU (forcing 4 spills and gains 3 % at best)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3)))   // <= 168 VGPRs: 3 workgroups per CU (4 would spill)
 attn_bwd_small_kernel(AttnArgs a) {
     using C = SmallCfg<HD>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -126,8 +144,10 @@ attn_bwd_small_kernel(AttnArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int fr = lane & 15, g = lane >> 4, qq = fr >> 2, p = fr & 3;
-    const int64_t b = blockIdx.x;
-    int h = blockIdx.y * 4 + wave;
+    // head group fastest: the workgroups that write the other head slices of the same token rows run at the same time
+    const int64_t b = blockIdx.y;
+    const int hg = blockIdx.x;
+    int h = hg * 4 + wave;
     const bool live = h < a.heads;
     h = live ? h : a.heads - 1;
     const int nq = (int)a.nq, nk = (int)a.nk;
@@ -140,11 +160,17 @@ attn_bwd_small_kernel(AttnArgs a) {
     // wave-private LDS: image slot 0 holds K during phase T and Q during phase N, slot 1 holds dO.  Two slots
     // instead of three is what lets a third workgroup fit on a CU; everything is written and read by the same
     // wave (DS operations of one wave execute in order), so no workgroup barrier is needed anywhere.
-    char* k_s = smem + wave * L::WAVE_BYTES;
+    char* k_s = smem + wave * L::IMG_BYTES;
     char* q_s = k_s;
-    char* do_s = k_s + L::IMG_BYTES;
-    float* lse_s = (float*)(do_s + L::IMG_BYTES);
+    char* do_s = smem + L::SLOT1_BASE + wave * L::IMG_BYTES;
+    float* lse_s = (float*)(smem + L::STATS_BASE) + wave * 2 * L::STAT_FLOATS;
     float* del_s = lse_s + L::STAT_FLOATS;
+    char* out0 = smem;                    // workgroup-shared staging regions (the four slot-0 / slot-1 images)
+    char* out1 = smem + L::SLOT1_BASE;
+    const int tid = threadIdx.x;
+    const int live_heads = a.heads - hg * 4;   // >= 1; heads past it are clamped duplicates, never stored
+    const int64_t hoff0 = (int64_t)hg * 4 * HD;
+    constexpr int OROW = 4 * HD * 2;      // bytes per staged output row
     const float sc = a.scale * LOG2E;
 
     // every global load of the (batch, head) item is issued before the first use: one exposed memory latency per
@@ -169,7 +195,6 @@ attn_bwd_small_kernel(AttnArgs a) {
     for (int t = 0; t < NKT; ++t) stage_tile<HD>(k_s, 16 * t, nk, fr, g, kf[t]);
 #pragma unroll
     for (int i = 0; i < NQT; ++i) {
-        stage_tile<HD>(do_s, 16 * i, nq, fr, g, dof[i]);
         // delta[q] = sum_d O[q][d] dO[q][d]; lse in log2 units
         float dl = 0.f;
 #pragma unroll
@@ -186,7 +211,6 @@ attn_bwd_small_kernel(AttnArgs a) {
     {
         const bf16x8 z[C::KCH] = {};
         if (NKT & 1) stage_tile<HD>(k_s, 16 * NKT, 0, fr, g, z);
-        if (NQT & 1) stage_tile<HD>(do_s, 16 * NQT, 0, fr, g, z);
     }
     asm volatile("" ::: "memory");   // compiler-only fence (see the forward kernel)
 
@@ -206,7 +230,8 @@ attn_bwd_small_kernel(AttnArgs a) {
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float pe = (16 * t + 4 * g + e) < nk ? exp2f(s[e] * sc - lse2) : 0.f;
+                float pe = __builtin_amdgcn_exp2f(fmaf(s[e], sc, -lse2));
+                if (t == NKT - 1) pe = (16 * t + 4 * g + e) < nk ? pe : 0.f;   // only the last key tile can be ragged
                 ds[t][e] = pe * (dp[e] - dl);
             }
         }
@@ -218,22 +243,29 @@ attn_bwd_small_kernel(AttnArgs a) {
             for (int ks = 0; ks < (NKT + 1) / 2; ++ks)
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<HD>(k_s, ks, dt, g, qq, p),
                                                               pack_pair(ds[2 * ks], ds[2 * ks + 1]), acc, 0, 0, 0);
-            if (live && q < nq) {
-                const bf16x4 ov = {(bf16)(acc[0] * a.scale), (bf16)(acc[1] * a.scale), (bf16)(acc[2] * a.scale), (bf16)(acc[3] * a.scale)};
-                *(bf16x4*)((bf16*)a.dq + b * a.dq_bs + (int64_t)q * a.dq_ts + hoff + dt * 16 + 4 * g) = ov;
-            }
+            // gradient tiles leave through LDS: 8-byte stores of 32-byte row pieces made the stores 55 % of the kernel
+            const bf16x4 ov = {(bf16)(acc[0] * a.scale), (bf16)(acc[1] * a.scale), (bf16)(acc[2] * a.scale), (bf16)(acc[3] * a.scale)};
+            *(bf16x4*)(out1 + q * OROW + wave * (HD * 2) + (dt * 16 + 4 * g) * 2) = ov;   // the slot-1 images are free until phase N
         }
     }
+    __syncthreads();
+    store_rows4<HD, NQT>(out1, (bf16*)a.dq + b * a.dq_bs + hoff0, a.dq_ts, nq, live_heads, tid);
+    __syncthreads();   // staging region read out: the waves may overwrite their slot-1 images
 
     // ---- phase N: dK, dV ---------------------------------------------------------------------------
     asm volatile("" ::: "memory");   // every transposed read of the K image is issued before slot 0 is overwritten
 #pragma unroll
-    for (int i = 0; i < NQT; ++i) stage_tile<HD>(q_s, 16 * i, nq, fr, g, qf[i]);   // slot 0: K image -> Q image
+    for (int i = 0; i < NQT; ++i) {
+        stage_tile<HD>(q_s, 16 * i, nq, fr, g, qf[i]);     // slot 0: K image -> Q image
+        stage_tile<HD>(do_s, 16 * i, nq, fr, g, dof[i]);   // slot 1: dQ staging -> dO image
+    }
     if (NQT & 1) {
         const bf16x8 z[C::KCH] = {};
         stage_tile<HD>(q_s, 16 * NQT, 0, fr, g, z);
+        stage_tile<HD>(do_s, 16 * NQT, 0, fr, g, z);
     }
     asm volatile("" ::: "memory");
+    bf16x4 dvo[NKT][C::DT], dko[NKT][C::DT];
 #pragma unroll
     for (int t = 0; t < NKT; ++t) {
         f32x4 pr[NQT + 1], ds[NQT + 1];
@@ -249,14 +281,14 @@ attn_bwd_small_kernel(AttnArgs a) {
             const f32x4 d4 = *(const f32x4*)(del_s + 16 * i + 4 * g);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float pe = (16 * i + 4 * g + e) < nq ? exp2f(s[e] * sc - l4[e]) : 0.f;
+                float pe = __builtin_amdgcn_exp2f(fmaf(s[e], sc, -l4[e]));
+                if (i == NQT - 1) pe = (16 * i + 4 * g + e) < nq ? pe : 0.f;   // only the last query tile can be ragged
                 pr[i][e] = pe;
                 ds[i][e] = pe * (dp[e] - d4[e]);
             }
         }
         pr[NQT] = f32x4{0.f, 0.f, 0.f, 0.f};
         ds[NQT] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int key = 16 * t + fr;
 #pragma unroll
         for (int dt = 0; dt < C::DT; ++dt) {
             f32x4 av = {0.f, 0.f, 0.f, 0.f}, ak = {0.f, 0.f, 0.f, 0.f};
@@ -267,14 +299,23 @@ attn_bwd_small_kernel(AttnArgs a) {
                 ak = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<HD>(q_s, qs, dt, g, qq, p),
                                                              pack_pair(ds[2 * qs], ds[2 * qs + 1]), ak, 0, 0, 0);
             }
-            if (live && key < nk) {
-                const bf16x4 vv = {(bf16)av[0], (bf16)av[1], (bf16)av[2], (bf16)av[3]};
-                const bf16x4 kk = {(bf16)(ak[0] * a.scale), (bf16)(ak[1] * a.scale), (bf16)(ak[2] * a.scale), (bf16)(ak[3] * a.scale)};
-                *(bf16x4*)((bf16*)a.dv + b * a.dv_bs + (int64_t)key * a.dv_ts + hoff + dt * 16 + 4 * g) = vv;
-                *(bf16x4*)((bf16*)a.dk + b * a.dk_bs + (int64_t)key * a.dk_ts + hoff + dt * 16 + 4 * g) = kk;
-            }
+            dvo[t][dt] = bf16x4{(bf16)av[0], (bf16)av[1], (bf16)av[2], (bf16)av[3]};
+            dko[t][dt] = bf16x4{(bf16)(ak[0] * a.scale), (bf16)(ak[1] * a.scale), (bf16)(ak[2] * a.scale), (bf16)(ak[3] * a.scale)};
         }
+        __builtin_amdgcn_sched_barrier(0);   // one key tile at a time: interleaving the unrolled tiles costs 60+ VGPRs
     }
+    // every wave's images are dead after this barrier: dV rows go out through the slot-0 region, dK rows through slot 1
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < NKT; ++t)
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt) {
+            *(bf16x4*)(out0 + (16 * t + fr) * OROW + wave * (HD * 2) + (dt * 16 + 4 * g) * 2) = dvo[t][dt];
+            *(bf16x4*)(out1 + (16 * t + fr) * OROW + wave * (HD * 2) + (dt * 16 + 4 * g) * 2) = dko[t][dt];
+        }
+    __syncthreads();
+    store_rows4<HD, NKT>(out0, (bf16*)a.dv + b * a.dv_bs + hoff0, a.dv_ts, nk, live_heads, tid);
+    store_rows4<HD, NKT>(out1, (bf16*)a.dk + b * a.dk_bs + hoff0, a.dk_ts, nk, live_heads, tid);
 }
 
 static bool small_ok(const AttnArgs& a, bool backward) {
@@ -290,8 +331,8 @@ bool attention_mfma_supported(const AttnArgs& a, bool backward) {
     if (a.q_ts % 8 || a.k_ts % 8 || a.v_ts % 8 || a.q_bs % 8 || a.k_bs % 8 || a.v_bs % 8 || a.o_ts % 8 || a.o_bs % 8) return false;
     if (!al(a.q, 16) || !al(a.k, 16) || !al(a.v, 16) || !al(a.o, 16)) return false;
     if (backward) {
-        if (a.dq_ts % 4 || a.dk_ts % 4 || a.dv_ts % 4 || a.dq_bs % 4 || a.dk_bs % 4 || a.dv_bs % 4) return false;
-        if (!al(a.d_o, 16) || !al(a.dq, 8) || !al(a.dk, 8) || !al(a.dv, 8)) return false;
+        if (a.dq_ts % 8 || a.dk_ts % 8 || a.dv_ts % 8 || a.dq_bs % 8 || a.dk_bs % 8 || a.dv_bs % 8) return false;
+        if (!al(a.d_o, 16) || !al(a.dq, 16) || !al(a.dk, 16) || !al(a.dv, 16)) return false;   // 16-byte gradient stores
     }
     return true;
 }
@@ -330,7 +371,7 @@ static void launch_bwd_small_one(const AttnArgs& a, dim3 grid, hipStream_t s) {
 
 template <int NQT>
 static int launch_bwd_small32(const AttnArgs& a, int nkt, hipStream_t s) {
-    dim3 grid((unsigned)a.batch, (unsigned)((a.heads + 3) / 4));
+    dim3 grid((unsigned)((a.heads + 3) / 4), (unsigned)a.batch);
 #define L(N) launch_bwd_small_one<NQT, N>(a, grid, s)
     switch (nkt) {
         case 1: L(1); break;
