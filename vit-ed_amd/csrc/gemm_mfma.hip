@@ -347,7 +347,9 @@ gemm_tn_mfma_kernel(const bf16* __restrict__ dY, int64_t lddy, const bf16* __res
 #ifdef TN_DBG_NO_MFMA
                     asm volatile("" ::"v"(af[i]), "v"(bf_[j]));
 #else
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf_[j], acc[i][j], 0, 0, 0);
+                    // transposed product (X fragment as the A operand): a lane then holds 4 CONSECUTIVE k of one n row,
+                    // so the slab leaves as 16-byte stores (dword stores of the n-major layout cost 6 % of the kernel)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf_[j], af[i], acc[i][j], 0, 0, 0);
 #endif
                 }
             if (BIAS && kc0 == 0) {
@@ -370,12 +372,14 @@ gemm_tn_mfma_kernel(const bf16* __restrict__ dY, int64_t lddy, const bf16* __res
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int64_t k = kc0 + wc * 64 + j * 16 + fr;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int64_t n = n0 + wr * 64 + i * 16 + fq * 4 + e;
-                if (n < N && k < K) o[n * K + k] = acc[i][j][e];
-            }
+            // acc[i][j]: row n = ... + fr, columns k = ... + 4 fq + (0..3); K % 8 == 0 makes the 4 columns all-or-nothing
+            const int64_t n = n0 + wr * 64 + i * 16 + fr;
+            const int64_t k = kc0 + wc * 64 + j * 16 + fq * 4;
+#ifdef TN_DBG_NO_STORE
+            asm volatile("" ::"v"(acc[i][j]));
+#else
+            if (n < N && k < K) *(f32x4*)(o + n * K + k) = acc[i][j];
+#endif
         }
     }
     if constexpr (BIAS) {
