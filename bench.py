@@ -72,6 +72,26 @@ def cpu_baseline(cfg_shape, seconds_budget=40.0):
             'sample': f'config A, batch {b}, fp32 eager CPU oracle, fwd+bwd, median of {len(times)} steps after 2 warm-ups'}
 
 
+def pmc_traffic(kernel_class, path=os.path.join(ROOT, 'profiles', 'r01_hbm_traffic_per_kernel.csv')):
+    """HBM bytes per launch of the dominant kernel class from the COMMITTED rocprofv3 PMC summary (FETCH_SIZE / WRITE_SIZE
+    passes cannot run inside this process; profiles/collect.sh + summarize.py regenerate the file): launch-weighted
+    mean over the class's template instances.  None when the file or the class is missing."""
+    try:
+        tot = n = 0.0
+        for line in open(path):
+            if line.startswith('#') or line.startswith('kernel,'):
+                continue
+            name, launches, _f, _w, total = line.rsplit(',', 4)
+            if kernel_class.split('(')[0] in name:
+                tot += float(launches) * float(total)
+                n += float(launches)
+        if n:
+            return {'traffic': round(tot / n * 1e6), 'traffic_unit': 'bytes/launch (rocprofv3 PMC, profiles/r01_hbm_traffic_per_kernel.csv)'}
+    except (OSError, ValueError):
+        pass
+    return {'traffic': None}
+
+
 class LaunchTimer:
     """Brackets every C-ABI contraction launch with HIP events on the launch stream."""
 
@@ -79,7 +99,7 @@ class LaunchTimer:
         self.ops, self.records = ops, []
         self._orig = {}
 
-    def _wrap(self, name, flops_fn, label_fn):
+    def _wrap(self, name, flops_fn, label_fn, bytes_fn=None):
         orig = getattr(self.ops, name)
         self._orig[name] = orig
 
@@ -89,7 +109,7 @@ class LaunchTimer:
             out = orig(*a, **k)
             e1.record()
             gp, ap = self.ops.last_paths()
-            self.records.append((label_fn(a, k, gp, ap), flops_fn(a, k), e0, e1))
+            self.records.append((label_fn(a, k, gp, ap), flops_fn(a, k), e0, e1, bytes_fn(a, k) if bytes_fn else 0.0))
             return out
         setattr(self.ops, name, wrapped)
 
@@ -99,6 +119,15 @@ class LaunchTimer:
             n = B.shape[0] if k.get('b_layout', 0) == 0 else B.shape[1]
             return 2.0 * A.shape[0] * A.shape[1] * n
 
+        def gemm_bytes(a, k):   # algorithmic HBM bytes of one contraction + its fused epilogue (operands once, outputs once)
+            A, B = a[0], a[1]
+            m, kk = A.shape
+            n = B.shape[0] if k.get('b_layout', 0) == 0 else B.shape[1]
+            es = A.element_size()
+            epi = k.get('epilogue', 0)
+            out = {0: es, 1: 2 * es, 2: 4 + 4, 3: es + es, 4: 4}.get(epi, es)   # store | z+gelu | residual in + fp32 out | aux in + out | fp32
+            return float(m * kk * es + n * kk * es + m * n * out)
+
         def tn_flops(a, k):
             dy, x = a[0], a[1]
             return 2.0 * dy.shape[0] * dy.shape[1] * x.shape[1]
@@ -107,7 +136,7 @@ class LaunchTimer:
             q, kk = a[0], a[1]
             return 4.0 * q.shape[0] * q.shape[1] * kk.shape[1] * q.shape[2]
 
-        self._wrap('gemm', gemm_flops, lambda a, k, gp, ap: 'gemm_nt_mfma_kernel' if gp == 2 else 'gemm_portable_kernel')
+        self._wrap('gemm', gemm_flops, lambda a, k, gp, ap: 'gemm_nt_mfma_kernel' if gp == 2 else 'gemm_portable_kernel', gemm_bytes)
         self._wrap('linear_bwd_weight', tn_flops, lambda a, k, gp, ap: 'gemm_tn_mfma_kernel(+slab/bias sums)' if gp == 2 else 'gemm_tn_portable_kernel')
         self._wrap('attention_fwd', attn_fwd_flops, lambda a, k, gp, ap: 'attn_fwd_mfma' if ap == 2 else 'attn_fwd_portable_kernel')
         self._wrap('attention_bwd', lambda a, k: 2.5 * attn_fwd_flops(a, k), lambda a, k, gp, ap: 'attn_bwd_mfma' if ap == 2 else 'attn_bwd_portable_kernels')
@@ -120,12 +149,13 @@ class LaunchTimer:
     def summary(self):
         torch.cuda.synchronize()
         agg = {}
-        for label, fl, e0, e1 in self.records:
+        for label, fl, e0, e1, nbytes in self.records:
             ms = e0.elapsed_time(e1)
-            d = agg.setdefault(label, {'launches': 0, 'ms': 0.0, 'flops': 0.0})
+            d = agg.setdefault(label, {'launches': 0, 'ms': 0.0, 'flops': 0.0, 'bytes': 0.0})
             d['launches'] += 1
             d['ms'] += ms
             d['flops'] += fl
+            d['bytes'] += nbytes
         return agg
 
 
@@ -181,8 +211,9 @@ def main():
         d = agg[dom]
         achieved = d['flops'] / (d['ms'] * 1e-3) / 1e12
         roof = {'roofline': {'bound': 'mfma', 'kernel': dom, 'achieved': round(achieved, 1), 'peak': PEAK_BF16_DENSE_TFLOPS,
-                             'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_BF16_DENSE_TFLOPS, 4), 'traffic': None,
-                             'avg_launch_us': round(1e3 * d['ms'] / d['launches'], 2), 'launches_per_step': d['launches'] // 2},
+                             'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_BF16_DENSE_TFLOPS, 4),
+                             'avg_launch_us': round(1e3 * d['ms'] / d['launches'], 2), 'launches_per_step': d['launches'] // 2,
+                             'algorithmic_bytes_per_launch': round(d['bytes'] / d['launches']), **pmc_traffic(dom)},
                 'kernels': kernels}
         step.flat.zero()
     if world > 1:
