@@ -80,10 +80,8 @@ class FlatGradients:
             dist.all_reduce(self.wire, op=dist.ReduceOp.SUM, group=group)
             self.flat.copy_(self.wire)
             self.flat.mul_(1.0 / world)
-        elif dist.get_backend(group) == 'nccl':
-            dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=group)   # RCCL divides inside the collective: no extra pass
         else:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)   # gloo has no AVG
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
             self.flat.mul_(1.0 / world)
 
     def clip_(self, max_norm: float):
