@@ -33,6 +33,7 @@ attn_fwd_small_kernel(AttnArgs a) {
     const bf16* kb = (const bf16*)a.k + b * a.k_bs + (int64_t)h * HD;
     const bf16* vb = (const bf16*)a.v + b * a.v_bs + (int64_t)h * HD;
     char* vs = smem + wave * C::TILE_BYTES;
+    char* os = smem + 4 * C::TILE_BYTES + wave * 16 * C::ROW_BYTES;   // output scratch: one 16-row tile per wave
 
     bf16x8 kf[NKT][C::KCH], qnext[C::KCH];
     load_row_frags<HD>(qb, a.q_ts, 0, nq, fr, g, qnext);   // query tiles are prefetched one iteration ahead
@@ -93,11 +94,24 @@ attn_fwd_small_kernel(AttnArgs a) {
                 const bf16x8 vt = tr_frag<HD>(vs, ks, dt, g, qq, p);
                 o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt, pack_pair(st[2 * ks], st[2 * ks + 1]), o, 0, 0, 0);
             }
-            if (live && q < nq) {
-                const bf16x4 ov = {(bf16)(o[0] * inv), (bf16)(o[1] * inv), (bf16)(o[2] * inv), (bf16)(o[3] * inv)};
-                *(bf16x4*)((bf16*)a.o + b * a.o_bs + (int64_t)q * a.o_ts + (int64_t)h * HD + dt * 16 + 4 * g) = ov;
+            // the 16 x HD output tile leaves through a wave-private LDS scratch as ONE 16-byte store per lane
+            // (16 token rows x HD * 2 bytes per instruction; 8-byte stores of 32-byte pieces cost ~10 % of the kernel)
+            const bf16x4 ov = {(bf16)(o[0] * inv), (bf16)(o[1] * inv), (bf16)(o[2] * inv), (bf16)(o[3] * inv)};
+            *(bf16x4*)(os + fr * C::ROW_BYTES + (dt * 16 + 4 * g) * 2) = ov;
+        }
+        asm volatile("" ::: "memory");
+        {
+            constexpr int CPR = C::ROW_BYTES / 16;            // 16-byte chunks per row: 4 (hd 32) or 8 (hd 64)
+#pragma unroll
+            for (int j = 0; j < 16 * CPR / 64; ++j) {
+                const int c = lane + 64 * j;
+                const int row = c / CPR, ch = c % CPR;
+                const bf16x8 v = *(const bf16x8*)(os + row * C::ROW_BYTES + ch * 16);
+                if (live && 16 * i + row < nq)
+                    *(bf16x8*)((bf16*)a.o + b * a.o_bs + (int64_t)(16 * i + row) * a.o_ts + (int64_t)h * HD + ch * 8) = v;
             }
         }
+        asm volatile("" ::: "memory");
         if (live && g == 0 && q < nq) a.lse[(b * a.heads + h) * a.nq + q] = (m + log2f(l)) * LN2;
     }
 }
@@ -341,7 +355,7 @@ template <int HD>
 static int launch_fwd_small(const AttnArgs& a, hipStream_t s) {
     const int nkt = (int)((a.nk + 15) / 16);
     dim3 grid((unsigned)a.batch, (unsigned)((a.heads + 3) / 4));
-    const size_t lds = 4 * SmallCfg<HD>::TILE_BYTES;
+    const size_t lds = 4 * SmallCfg<HD>::TILE_BYTES + 4 * 16 * SmallCfg<HD>::ROW_BYTES;
 #define L(N) hipLaunchKernelGGL((attn_fwd_small_kernel<HD, N>), grid, dim3(256), lds, s, a)
     switch (nkt) {
         case 1: L(1); break;
