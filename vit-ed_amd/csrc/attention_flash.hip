@@ -20,7 +20,9 @@
 #include "attention_tiles.h"
 
 #define FL_TILE 64   // keys (or queries) per LDS tile
+#ifndef FL_W
 #define FL_W 2       // 16-row tiles per wave
+#endif
 
 template <int HD> struct FlashCfg {
     using C = SmallCfg<HD>;
