@@ -406,7 +406,8 @@ bool gemm_tn_mfma_supported(const void* dY, int64_t lddy, const void* X, int64_t
 // in ONE round - one workgroup more than a round costs a whole extra round.
 int64_t gemm_tn_mfma_splits(int64_t M, int64_t N, int64_t K) {
     const int64_t tiles = ceil_div64(N, 128) * ceil_div64(K, 128);
-    int64_t s = TN_SLOTS / tiles;
+    static const int64_t slots = getenv("VITED_TN_SLOTS") ? atoi(getenv("VITED_TN_SLOTS")) : TN_SLOTS;   // tuning override
+    int64_t s = slots / tiles;
     const int64_t max_s = ceil_div64(M, 512);
     if (s > max_s) s = max_s;
     if (s < 1) s = 1;
