@@ -171,3 +171,26 @@ def test_pairwise_similarity_sharded_equals_naive(tmp_path):
     mp.spawn(_sim_worker, args=(2, 29900 + os.getpid() % 90, out), nprocs=2, join=True)
     two = torch.load(out, weights_only=True)
     assert torch.equal(two, one)            # 2 ranks + all-gather give bit-identical scores to 1 rank
+
+
+def test_mine_pairs_matches_the_reference_loop():
+    """engine.mine_pairs vs a literal restatement of hisfrag.py:117-145 (loop over i, nonzero per row): same positives
+    in the same order, negatives a subset of the reference's candidates with the reference's count."""
+    import torch
+    import vited_amd
+    eng = vited_amd.engine
+    g = torch.Generator().manual_seed(5)
+    for n, classes in ((24, 8), (7, 2), (5, 5), (6, 1)):
+        targets = torch.randint(0, classes, (n,), generator=g)
+        pos_ref, neg_ref = [], []
+        for i in range(n):
+            for j in range(i + 1, n):
+                (pos_ref if targets[i] == targets[j] else neg_ref).append((i, j))
+        groups, labels = eng.mine_pairs(targets, generator=torch.Generator().manual_seed(1))
+        npos = len(pos_ref)
+        nneg = min(len(neg_ref), 2 * npos)
+        assert groups.shape == (npos + nneg, 2) and labels.shape == (npos + nneg, 1)
+        assert [tuple(r) for r in groups[:npos].tolist()] == pos_ref
+        got_neg = [tuple(r) for r in groups[npos:].tolist()]
+        assert len(set(got_neg)) == nneg and set(got_neg) <= set(neg_ref)
+        assert labels[:npos].eq(1).all() and labels[npos:].eq(0).all()

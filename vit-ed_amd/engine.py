@@ -244,6 +244,39 @@ class TrainStep:
 
 
 # ---------------------------------------------------------------------------------------------
+# pair mining for the two-stage HisFrag training step (hisfrag.py:117-159)
+# ---------------------------------------------------------------------------------------------
+def mine_pairs(targets: torch.Tensor, neg_per_pos: float = 2.0, generator=None):
+    """(groups int64 [P, 2], labels fp32 [P, 1]): every same-label pair (i, j), j > i, in row-major order, then a
+    random subset of the different-label pairs of size min(#neg, int(neg_per_pos * #pos)) - what
+    ``HisfragTrainer.prepare_data`` (hisfrag.py:117-145) builds with a Python loop over the batch and 2n
+    ``nonzero`` host syncs.  Here: one ``triu_indices`` + two boolean selects on the device (the pair count is
+    data-dependent, so one host sync per step remains)."""
+    t = targets.reshape(-1)
+    n = t.numel()
+    i, j = torch.triu_indices(n, n, offset=1, device=t.device)
+    same = t[i] == t[j]
+    pos = torch.stack([i[same], j[same]], dim=1)
+    neg = torch.stack([i[~same], j[~same]], dim=1)
+    keep = min(neg.shape[0], int(neg_per_pos * pos.shape[0]))
+    perm = torch.randperm(neg.shape[0], generator=generator, device=neg.device if generator is None else generator.device)[:keep]
+    neg = neg[perm.to(neg.device)]
+    groups = torch.cat([pos, neg], dim=0)
+    labels = torch.cat([torch.ones(pos.shape[0], device=t.device), torch.zeros(neg.shape[0], device=t.device)]).view(-1, 1)
+    return groups, labels
+
+
+def hisfrag_prepare_data(model, samples: torch.Tensor, targets: torch.Tensor, amp: bool = True, generator=None):
+    """The first half of the reference's two-stage step (hisfrag.py:117-155): mine pairs, run the encoder ONCE per
+    image, gather.  Returns ((x, x1_feats), labels) for ``model(x1_feats, x)`` exactly like the reference's
+    ``prepare_data`` -> ``train_step`` hand-off (hisfrag.py:153-159)."""
+    groups, labels = mine_pairs(targets, generator=generator)
+    with torch.autocast(samples.device.type, dtype=torch.bfloat16, enabled=amp):
+        feats = model(samples, forward_first_part=True)
+    return (samples[groups[:, 0]], feats[groups[:, 1]]), labels
+
+
+# ---------------------------------------------------------------------------------------------
 # pairwise similarity-matrix inference (hisfrag.py:161-302, BASELINE config 5)
 # ---------------------------------------------------------------------------------------------
 def shard_rows_by_pair_count(n: int, world: int):
