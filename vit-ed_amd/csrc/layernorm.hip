@@ -219,18 +219,19 @@ layernorm_bwd_kernel(const T* __restrict__ dy, int64_t dy_ld, const float* __res
 
 // out[c] = sum_p partial[p][c]; block = 16 columns x 16 partial-row groups (a coalesced 64-byte read per
 // group and step), LDS combine: 4x more workgroups and 4x shorter loops than a 64-column block
-__global__ void __launch_bounds__(256)
+#define LNF_GROUPS 64   // row groups per workgroup (1024 threads = 16 columns x 64 groups): 12 dependent loads per thread at 768 partial rows
+__global__ void __launch_bounds__(16 * LNF_GROUPS)
 ln_bwd_finish_kernel(const float* __restrict__ partial, int nparts, int width, float* __restrict__ dgamma,
                      float* __restrict__ dbeta, int dim, int accumulate) {
-    __shared__ float red[16][17];
+    __shared__ float red[LNF_GROUPS][17];
     const int cx = threadIdx.x & 15, py = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cx;
     float a0 = 0.f, a1 = 0.f;
     if (c < width) {
         int p = py;
-        for (; p + 16 < nparts; p += 32) {
+        for (; p + LNF_GROUPS < nparts; p += 2 * LNF_GROUPS) {
             a0 += partial[(size_t)p * width + c];
-            a1 += partial[(size_t)(p + 16) * width + c];
+            a1 += partial[(size_t)(p + LNF_GROUPS) * width + c];
         }
         if (p < nparts) a0 += partial[(size_t)p * width + c];
     }
@@ -239,7 +240,7 @@ ln_bwd_finish_kernel(const float* __restrict__ partial, int nparts, int width, f
     if (py == 0 && c < width) {
         float v = 0.f;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) v += red[k][cx];
+        for (int k = 0; k < LNF_GROUPS; ++k) v += red[k][cx];
         float* dst = c < dim ? dgamma + c : dbeta + (c - dim);
         *dst = accumulate ? *dst + v : v;
     }
@@ -276,7 +277,7 @@ static int ln_bwd_launch(const void* dy, int64_t dy_ld, const float* x, int64_t 
         default: L(8); break;
     }
 #undef L
-    hipLaunchKernelGGL(ln_bwd_finish_kernel, dim3((2 * dim + 15) / 16), dim3(256), 0, s, ws, (int)blocks, 2 * dim, dgamma, dbeta, dim, accumulate);
+    hipLaunchKernelGGL(ln_bwd_finish_kernel, dim3((2 * dim + 15) / 16), dim3(16 * LNF_GROUPS), 0, s, ws, (int)blocks, 2 * dim, dgamma, dbeta, dim, accumulate);
     return vited_check_launch();
 }
 
