@@ -88,7 +88,7 @@ def test_slice_rows_cls_and_sum_rows(vited, gpu):
     assert torch.equal(ops.sum_rows(t), ops.sum_rows(t))
 
 
-@pytest.mark.parametrize('rows,dim', [(1, 32), (65, 384), (1000, 384), (130, 768), (7, 48)])
+@pytest.mark.parametrize('rows,dim', [(1, 32), (65, 384), (1000, 384), (130, 768), (7, 48), (33280, 384), (24601, 384)])
 def test_layernorm_fwd_bwd(vited, gpu, rows, dim):
     ops = vited.ops
     x = _rand((rows, dim), gpu, rows, 2.0) + 0.5
@@ -177,6 +177,45 @@ def test_gemm_all_epilogues(vited, gpu, dtype, M, N, K):
     F.gelu(xg).sum().backward()
     dz = ops.gemm(a, w, epilogue=L.EPI_MUL_GELU_GRAD, aux=aux)
     torch.testing.assert_close(dz.double(), _gemm_ref(a, w, None) * xg.grad, **tol)
+
+
+@pytest.mark.parametrize('M,N,K', [(8192, 1152, 384), (8321, 768, 384), (16640, 1536, 384), (8257, 384, 1536), (8320, 384, 384),
+                                   (9000, 384, 1152)])
+def test_gemm_bench_scale_tiles(vited, gpu, M, N, K):
+    """The tile variants only large launches select (256-row / 8-wave tiles for M >= 8192, BK = 64 at N = 384, the
+    XCD-aware tile order over thousands of tiles) with ragged last row tiles (M % 128 != 0): every epilogue, every output
+    element, against fp64 on the same bf16-rounded operands; plus the weight-gradient kernel's full split-K geometry."""
+    ops, L = vited.ops, vited._lib
+    a = _rand((M, K), gpu, 21, dtype=torch.bfloat16)
+    w = _rand((N, K), gpu, 22, 1 / math.sqrt(K), dtype=torch.bfloat16)
+    bias = _rand((N,), gpu, 23)
+    ref = _gemm_ref(a, w, bias)
+    out = ops.gemm(a, w, bias=bias)
+    assert ops.last_paths()[0] == 2
+    torch.testing.assert_close(out.double(), ref, **BF16_OUT)
+    z, u = ops.gemm(a, w, epilogue=L.EPI_GELU, bias=bias)
+    torch.testing.assert_close(z.double(), ref, **BF16_OUT)
+    torch.testing.assert_close(u.double(), F.gelu(ref), **BF16_OUT)
+    res = _rand((M, N), gpu, 24)
+    y = ops.gemm(a, w, epilogue=L.EPI_RESIDUAL, bias=bias, residual=res)
+    torch.testing.assert_close(y.double(), ref + res.double(), rtol=2e-4, atol=2e-4)
+    aux = _rand((M, N), gpu, 25, dtype=torch.bfloat16)
+    xg = aux.double().requires_grad_()
+    F.gelu(xg).sum().backward()
+    dz = ops.gemm(a, w, epilogue=L.EPI_MUL_GELU_GRAD, aux=aux)
+    torch.testing.assert_close(dz.double(), _gemm_ref(a, w, None) * xg.grad, **BF16_OUT)
+    o32 = ops.gemm(a, w, epilogue=L.EPI_STORE_F32)
+    torch.testing.assert_close(o32.double(), _gemm_ref(a, w, None), rtol=2e-4, atol=2e-4)
+    # dW = dY^T X and dbias over all M rows (512 workgroups, ragged last split), also accumulated onto existing values
+    dy = _rand((M, N), gpu, 26, dtype=torch.bfloat16)
+    dw, db = ops.linear_bwd_weight(dy, a)
+    dw_ref = dy.double().t() @ a.double()
+    torch.testing.assert_close(dw.double(), dw_ref, rtol=2e-4, atol=2e-3)
+    torch.testing.assert_close(db.double(), dy.double().sum(0), rtol=2e-4, atol=2e-3)
+    acc_w, acc_b = torch.ones(N, K, device=gpu), torch.full((N,), 2.0, device=gpu)
+    ops.linear_bwd_weight(dy, a, dw_out=acc_w, db_out=acc_b)
+    torch.testing.assert_close(acc_w.double(), dw_ref + 1, rtol=2e-4, atol=2e-3)
+    torch.testing.assert_close(acc_b.double(), dy.double().sum(0) + 2, rtol=2e-4, atol=2e-3)
 
 
 _AS_CHILD = """
@@ -272,7 +311,8 @@ def _sdpa_ref(q, k, v, heads, scale):
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('B,H,Nq,Nk,hd', [(3, 12, 64, 64, 32), (3, 12, 65, 65, 32), (2, 12, 65, 64, 32), (2, 6, 257, 256, 64),
                                           (1, 6, 1025, 1024, 64), (2, 1, 5, 4, 32), (1, 2, 1, 1, 64), (2, 3, 200, 130, 32),
-                                          (1, 6, 1024, 1024, 64), (1, 6, 1025, 1025, 64), (2, 2, 65, 65, 64), (1, 4, 129, 81, 32)])
+                                          (1, 6, 1024, 1024, 64), (1, 6, 1025, 1025, 64), (2, 2, 65, 65, 64), (1, 4, 129, 81, 32),
+                                          (300, 12, 65, 64, 32), (257, 6, 64, 64, 32), (129, 5, 65, 65, 32)])
 def test_attention_fwd_bwd(vited, gpu, dtype, B, H, Nq, Nk, hd):
     ops = vited.ops
     D = H * hd
