@@ -10,9 +10,9 @@
 // stage's DMA in flight under the current stage's MFMAs.  LDS images are XOR-swizzled on the
 // SOURCE address (the DMA destination is lane-linear) with the matching XOR on the read, so the
 // ds_read_b128 / ds_read_b64_tr_b16 fragment reads are bank-conflict free.
-// The NT epilogue is staged through LDS so every global access is a 16-byte, row-contiguous one, and
-// the epilogue operands that do not depend on the accumulators (residual rows, saved pre-activation,
-// bias) are fetched BEFORE the main loop so their HBM latency hides under the MFMAs.
+// The NT epilogue is staged through a wave-private LDS scratch so every global access is a 16-byte,
+// row-contiguous one; its operands (residual rows, saved pre-activation, bias) are fetched after the K loop,
+// one 16-row sub-tile ahead (held across the loop they cost a workgroup per CU).
 #include <stdlib.h>
 
 #include "gemm_kernels.h"
@@ -211,9 +211,9 @@ int gemm_nt_mfma(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t
 // TN (weight gradient): stage = dY tile [64 m][128 n] + X tile [64 m][128 k], 256-byte rows.
 // Image (b) of the guide's dual-use layouts: chunk ch of row r lives at ch ^ (((r&3)<<2)|((r>>2)&3));
 // both MFMA operands are read column-wise with ds_read_b64_tr_b16.
-// The bias gradient rides along: the workgroups of the first k-tile column multiply their dY
-// fragments by an all-ones B operand (4 extra MFMAs per 32 rows, on one wave column), which leaves
-// sum_m dY[m, n] in every column of a 16 x 16 accumulator.
+// The product is issued transposed (X fragment as the A operand) so a lane holds 4 consecutive k of one n row and
+// the slab leaves as 16-byte stores.  The bias gradient rides along: the workgroups of the first k-tile column
+// sum their dY fragments with v_dot2_f32_bf16 against packed ones (VALU, co-issued under the MFMAs).
 // ================================================================================================
 #ifndef TN_TM
 #define TN_TM 64

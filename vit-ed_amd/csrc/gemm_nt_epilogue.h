@@ -6,7 +6,7 @@
 //                  segment, 4 rows per store instruction.
 // Every global access of the epilogue (bias, residual, saved pre-activation, outputs) is therefore a
 // full-cache-line, 16-byte-per-lane access.  Operands that do not depend on the accumulators are
-// fetched into registers BEFORE the main loop (EpiPrefetch).
+// fetched into registers one sub-tile ahead of their use (EpiPrefetch), after the main loop.
 #pragma once
 #include "gemm_epilogue.h"
 
