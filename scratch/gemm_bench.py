@@ -3,7 +3,8 @@ sys.path.insert(0, '.')
 import vited_amd as v
 ops, L = v.ops, v._lib
 dev = torch.device('cuda:0')
-M = 65536
+import os
+M = int(os.environ.get("GB_M", 65536))
 def timeit(fn, n=20):
     for _ in range(3): fn()
     torch.cuda.synchronize()
