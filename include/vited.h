@@ -143,6 +143,28 @@ int vited_linear_bwd_weight(const void* dY, int64_t lddy, const void* X, int64_t
                             int64_t N, int64_t K, float* dW, float* dbias, int accumulate, float* workspace,
                             int64_t workspace_bytes, void* stream);
 
+/* ---- optimizer step on the flat gradient buffer ----------------- */
+
+/* Gradient clip + AdamW + bf16 weight-shadow refresh + gradient zeroing in two launches; replaces
+ * clip_grad_norm_ + optimizer.step() + zero_grad() of misc/utils.py:215-223 / misc/engine.py:231 and the
+ * torch.optim.AdamW that misc/optimizer.py:25-27 builds (same update rule; parity in tests/test_gpu_optim.py).
+ *   desc        DEVICE array of count x 10 int64, one row per parameter:
+ *               {p fp32 [rows, cols], g fp32 (its slice of grad_flat), exp_avg, exp_avg_sq, shadow bf16 [rows, cols] or 0,
+ *                shadow_t bf16 [cols, rows] or 0, rows, cols, first_tile, group}
+ *               first_tile = running sum of ceil(rows/64) * ceil(cols/64); total_tiles the sum over all rows.
+ *   grad_flat   the contiguous fp32 gradient buffer every g points into (the L2 norm is taken over all of it)
+ *   hyper       DEVICE fp32 array: [0] = number of updates done so far (the call increments it: bias correction uses
+ *               the incremented value), [1..7] unused, then 8 floats per parameter group
+ *               {lr, beta1, beta2, eps, weight_decay, 0, 0, 0} - device-resident so that a replayed hipGraph follows
+ *               lr_scheduler.step_update (misc/engine.py:228)
+ *   max_norm    clip_grad_norm_ threshold (<= 0: no clipping); norm_out (nullable) receives the pre-clip norm
+ *   zero_grad   != 0: every g is zeroed after it was read
+ *   workspace   >= vited_adamw_workspace_bytes() */
+int64_t vited_adamw_workspace_bytes(void);
+int vited_adamw_step(const int64_t* desc, int count, int64_t total_tiles, const float* grad_flat, int64_t grad_numel,
+                     float* hyper, float max_norm, int zero_grad, float* norm_out, float* workspace,
+                     int64_t workspace_bytes, void* stream);
+
 /* ---- attention core (F.scaled_dot_product_attention, vision_transformer.py:63-66,183-186) ----- */
 
 /* o[b, i, h, :] = softmax_j(scale * q[b,i,h,:] . k[b,j,h,:]) v[b,j,h,:]   (no mask, no dropout)

@@ -6,7 +6,7 @@ root.  Public surface: ``build_model``, ``get_config`` / ``config_from_yaml``,
 ``VisionTransformerCustom``, the ``ops`` (functional C-ABI wrappers) and ``torch.ops.vited.*`` (the same
 kernels as PyTorch custom operators, ``custom_ops.py``).
 """
-from . import _lib, config, custom_ops, engine, functions, ops  # noqa: F401  (custom_ops registers torch.ops.vited.*)
+from . import _lib, config, custom_ops, engine, functions, ops, optim  # noqa: F401  (custom_ops registers torch.ops.vited.*)
 from .build import build_model  # noqa: F401
 from .config import config_from_yaml, get_config  # noqa: F401
 from .model import VisionTransformerCustom  # noqa: F401

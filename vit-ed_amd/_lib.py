@@ -42,6 +42,8 @@ SIGNATURES = {
                         _i64, _i, _p]),
     'vited_linear_bwd_weight_workspace_bytes': (_i64, [_i64, _i64, _i64]),
     'vited_linear_bwd_weight': (_i, [_p, _i64, _p, _i64, _i, _i64, _i64, _i64, _p, _p, _i, _p, _i64, _p]),
+    'vited_adamw_workspace_bytes': (_i64, []),
+    'vited_adamw_step': (_i, [_p, _i, _i64, _p, _i64, _p, _f, _i, _p, _p, _i64, _p]),
     'vited_attention_fwd': (_i, [_p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _p, _i, _i64, _i,
                                  _i64, _i64, _i, _f, _p]),
     'vited_attention_bwd': (_i, [_p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _p, _p, _i64, _i64, _p, _p,

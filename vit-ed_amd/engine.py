@@ -41,29 +41,69 @@ def configure_ddp(backend: str | None = None):
 # ---------------------------------------------------------------------------------------------
 # flat gradient buffer + all-reduce (replaces DistributedDataParallel, misc/engine.py:75)
 # ---------------------------------------------------------------------------------------------
+def _avg_supported(group=None) -> bool:
+    """ReduceOp.AVG exists on the nccl (= RCCL) backend only; gloo has SUM."""
+    return dist.is_initialized() and dist.get_backend(group) == 'nccl'
+
+
 class FlatGradients:
     """All parameter gradients as views of ONE contiguous fp32 buffer.
 
     ``p.grad`` is pre-set to a view, so autograd accumulates in place and the buffer is always the
     gradient; ``zero()`` replaces ``optimizer.zero_grad()``; ``all_reduce_mean()`` is the data-parallel
     exchange: one RCCL all-reduce of the whole buffer (133 MB fp32 at config A - SURVEY.md 2.3 C1 -
-    instead of six 25 MB buckets), optionally bf16-compressed on the wire."""
+    instead of six 25 MB buckets), optionally bf16-compressed on the wire.
 
-    def __init__(self, params, compress_bf16: bool = False):
-        self.params = [p for p in params if p.requires_grad]
-        if not self.params:
+    ``early`` (an iterable of parameters) are laid out FIRST: ``buckets()`` then yields two contiguous
+    ranges, [early | rest].  TrainStep passes the decoder-only parameters there - their gradients are
+    final when the decoder's backward returns, so their all-reduce can run under the encoder's backward
+    (the overlap c10d's DDP reducer gives the reference, misc/engine.py:75)."""
+
+    def __init__(self, params, compress_bf16: bool = False, early=None):
+        params = [p for p in params if p.requires_grad]
+        if not params:
             raise ValueError('no trainable parameters')
+        early_ids = {id(p) for p in (early or ())}
+        first = [p for p in params if id(p) in early_ids]
+        rest = [p for p in params if id(p) not in early_ids]
+        self.params = first + rest
         dev = self.params[0].device
         total = sum(p.numel() for p in self.params)
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
         self.wire = torch.empty(total, dtype=torch.bfloat16, device=dev) if compress_bf16 else None
         off = 0
-        self.views = []
+        self.views, self.offsets = [], []
         for p in self.params:
             v = self.flat[off: off + p.numel()].view_as(p)
             p.grad = v
             self.views.append(v)
+            self.offsets.append(off)
             off += p.numel()
+        self.split = sum(p.numel() for p in first)     # [0, split) = early bucket, [split, total) = the rest
+        self._pending = []
+
+    def buckets(self):
+        total = self.flat.numel()
+        return [(0, self.split), (self.split, total)] if 0 < self.split < total else [(0, total)]
+
+    def attach(self):
+        """Make every ``p.grad`` the flat view again.  ``optimizer.zero_grad()`` (the reference's loop,
+        misc/engine.py:231; set_to_none=True by default since torch 2.0) detaches them: a parameter whose grad
+        is None gets its view back ZEROED, one that received a fresh tensor has it copied into the view."""
+        detached = [(p, v) for p, v in zip(self.params, self.views) if p.grad is not v]
+        if not detached:
+            return 0
+        if len(detached) == len(self.params) and all(p.grad is None for p, _ in detached):
+            self.flat.zero_()                      # the common case: one fill instead of one per parameter
+        else:
+            for p, v in detached:
+                if p.grad is None:
+                    v.zero_()
+                else:
+                    v.copy_(p.grad)
+        for p, v in detached:
+            p.grad = v
+        return len(detached)
 
     def zero(self):
         self.flat.zero_()
@@ -71,18 +111,36 @@ class FlatGradients:
             if p.grad is not v:          # someone called zero_grad(set_to_none=True): re-attach
                 p.grad = v
 
-    def all_reduce_mean(self, group=None):
+    # -- the exchange ------------------------------------------------------------------------
+    def start_all_reduce(self, lo: int, hi: int, group=None):
+        """Launch the mean all-reduce of flat[lo:hi] WITHOUT waiting for it (RCCL runs it on the process
+        group's own stream behind everything already queued on the current stream).  ``finish_all_reduce``
+        joins."""
         world = dist.get_world_size(group) if dist.is_initialized() else 1
-        if world == 1:
+        if world == 1 or hi <= lo:
             return
+        seg = self.flat[lo:hi]
         if self.wire is not None:
-            self.wire.copy_(self.flat)
-            dist.all_reduce(self.wire, op=dist.ReduceOp.SUM, group=group)
-            self.flat.copy_(self.wire)
-            self.flat.mul_(1.0 / world)
+            buf = self.wire[lo:hi]
+            buf.copy_(seg)
         else:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
-            self.flat.mul_(1.0 / world)
+            buf = seg
+        avg = _avg_supported(group)
+        work = dist.all_reduce(buf, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=group, async_op=True)
+        self._pending.append((work, seg, buf, None if avg else 1.0 / world))
+
+    def finish_all_reduce(self):
+        for work, seg, buf, scale in self._pending:
+            work.wait()                       # the current stream now waits for the collective
+            if buf is not seg:
+                seg.copy_(buf)
+            if scale is not None:
+                seg.mul_(scale)
+        self._pending = []
+
+    def all_reduce_mean(self, group=None):
+        self.start_all_reduce(0, self.flat.numel(), group)
+        self.finish_all_reduce()
 
     def clip_(self, max_norm: float):
         """clip_grad_norm_ on the flat buffer: one norm kernel instead of 280 (misc/utils.py:215-217)."""
@@ -93,11 +151,21 @@ class FlatGradients:
 
 
 def broadcast_parameters(model, src: int = 0, group=None):
-    """DDP ctor semantics: every rank starts from rank 0's parameters."""
+    """DDP ctor semantics: every rank starts from rank 0's parameters - as ONE
+    broadcast of a flattened copy (the reference's DDP ctor also coalesces) instead of one per tensor."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
-    for p in model.parameters():
-        dist.broadcast(p.data, src=src, group=group)
+    params = [p.data for p in model.parameters()]
+    by_dtype = {}
+    for p in params:
+        by_dtype.setdefault(p.dtype, []).append(p)
+    for ps in by_dtype.values():
+        flat = torch.cat([p.reshape(-1) for p in ps])
+        dist.broadcast(flat, src=src, group=group)
+        off = 0
+        for p in ps:
+            p.copy_(flat[off: off + p.numel()].view_as(p))
+            off += p.numel()
 
 
 # ---------------------------------------------------------------------------------------------
@@ -112,13 +180,25 @@ def param_groups_no_decay_1d(model):
     return [{'params': decay}, {'params': no_decay, 'weight_decay': 0.}]
 
 
-def build_optimizer(config, model):
+def build_optimizer(config, model, capturable: bool = False, fused_hip: bool | None = None):
+    """misc/optimizer.py:10-46: AdamW / SGD with the no-decay group for 1-D parameters and ``*.bias``.
+
+    On a GPU model AdamW is ``optim.FlatAdamW`` (the HIP multi-tensor kernel: clip + AdamW + bf16 weight-shadow
+    refresh in one pass, hipGraph-replayable with a per-iteration learning rate); ``fused_hip=False`` gives
+    ``torch.optim.AdamW(fused=True)`` instead, with ``capturable`` forwarded (a torch optimizer captured into a
+    hipGraph must be built with capturable=True, and TrainStep keeps its learning rate in a device tensor)."""
     name = config.TRAIN.OPTIMIZER.NAME.lower()
     groups = param_groups_no_decay_1d(model)
-    fused = all(p.is_cuda for g in groups for p in g['params'])
+    on_gpu = all(p.is_cuda for g in groups for p in g['params'])
     if name == 'adamw':
-        return torch.optim.AdamW(groups, eps=config.TRAIN.OPTIMIZER.EPS, betas=tuple(config.TRAIN.OPTIMIZER.BETAS),
-                                 lr=config.TRAIN.BASE_LR, weight_decay=config.TRAIN.WEIGHT_DECAY, fused=fused)
+        kw = dict(eps=config.TRAIN.OPTIMIZER.EPS, betas=tuple(config.TRAIN.OPTIMIZER.BETAS), lr=config.TRAIN.BASE_LR,
+                  weight_decay=config.TRAIN.WEIGHT_DECAY)
+        if on_gpu and (fused_hip is None or fused_hip):
+            from .optim import FlatAdamW
+            return FlatAdamW(groups, **kw)
+        if on_gpu:
+            return torch.optim.AdamW(groups, fused=True, capturable=capturable, **kw)
+        return torch.optim.AdamW(groups, **kw)
     if name == 'sgd':
         return torch.optim.SGD(groups, momentum=config.TRAIN.OPTIMIZER.MOMENTUM, nesterov=True, lr=config.TRAIN.BASE_LR,
                                weight_decay=config.TRAIN.WEIGHT_DECAY)
@@ -127,17 +207,26 @@ def build_optimizer(config, model):
 
 class NativeScalerWithGradNormCount:
     """Call-compatible with misc/utils.py:206-232.  bf16 needs no loss scaling, so ``scale`` is 1;
-    the call still does backward -> (all-reduce) -> clip -> step and returns the gradient norm."""
+    the call still does backward -> (all-reduce) -> clip -> step and returns the gradient norm.
+
+    With ``flat`` (a FlatGradients) the gradients live in one buffer that is all-reduced and clipped as a
+    whole.  The reference's loop calls ``optimizer.zero_grad()`` after every update (misc/engine.py:231),
+    which DETACHES ``p.grad`` from the buffer (set_to_none), so the views are re-attached (and zeroed)
+    before every backward - otherwise the exchange and the clip would act on a stale buffer while the
+    optimizer consumed un-reduced gradients."""
     state_dict_key = 'amp_scaler'
 
     def __init__(self, flat: FlatGradients | None = None):
         self.flat = flat
 
     def __call__(self, loss, optimizer, clip_grad=None, parameters=None, create_graph=False, update_grad=True):
+        if self.flat is not None:
+            self.flat.attach()
         loss.backward(create_graph=create_graph)
         if not update_grad:
             return None
         if self.flat is not None:
+            self.flat.attach()     # a backward that found grad=None would have allocated fresh tensors: fold them in
             self.flat.all_reduce_mean()
             norm = self.flat.clip_(clip_grad) if clip_grad is not None else torch.linalg.vector_norm(self.flat.flat)
         else:
@@ -159,38 +248,123 @@ class NativeScalerWithGradNormCount:
 # ---------------------------------------------------------------------------------------------
 # the per-iteration body of train_one_epoch (misc/engine.py:202-231), hipGraph-replayable
 # ---------------------------------------------------------------------------------------------
-class TrainStep:
-    """forward (autocast) -> BCE-with-logits -> backward -> flat all-reduce -> clip 5.0 -> AdamW -> zero.
+def _decoder_only_parameters(model):
+    """Parameters whose gradient is complete once the decoder + head backward has run: everything except the
+    encoder blocks and the tensors both image paths share (patch_embed.*, pos_embed get gradient from the
+    encoder too, vision_transformer.py:379,391-392)."""
+    out = []
+    for name, p in model.named_parameters():
+        if name.startswith(('cross_blocks.', 'norm.', 'head.')) or name == 'cls_token':
+            out.append(p)
+    return out
 
-    ``use_graph=True`` captures forward+backward (and, separately, clip+optimizer) into hipGraphs
-    after one eager warm-up step, with the RCCL all-reduce issued eagerly between the two replays,
-    so the ~900 launches of a step cost two graph launches on the host."""
+
+class TrainStep:
+    """forward (autocast) -> BCE-with-logits / accumulation_steps -> backward -> flat all-reduce -> clip 5.0 ->
+    optimizer step -> lr_scheduler.step_update -> zero   (misc/engine.py:202-231).
+
+    * ``accumulation_steps`` > 1: gradients accumulate in the flat buffer over that many calls and the
+      exchange / clip / update happen on the last one (the reference all-reduces on every micro-step because
+      it never uses ``no_sync()``; the mean of sums is the same number).
+    * The exchange is split in two buckets: the decoder-only gradients are all-reduced while the encoder's
+      backward still runs (``overlap=True``; needs a model with the reference's 3-way forward), the rest
+      after it.  The backward is driven in two stages for that: decoder + head first, then the encoder from
+      the gradient of the features.
+    * ``use_graph=True`` replays hipGraphs (forward + decoder backward | encoder backward | update) captured
+      after two eager warm-up steps, with the RCCL all-reduces issued between the replays, so the ~900
+      launches of a step cost three graph launches on the host.  The learning rate lives in a device scalar,
+      so ``lr_scheduler.step_update`` / ``set_lr`` take effect in the replayed update."""
 
     def __init__(self, model, optimizer, *, clip_grad=5.0, amp=True, criterion=None, use_graph=False,
-                 compress_bf16=False, forward_fn=None):
+                 compress_bf16=False, forward_fn=None, accumulation_steps=1, lr_scheduler=None, overlap=True, group=None):
         self.model, self.optimizer, self.clip_grad, self.amp = model, optimizer, clip_grad, amp
         self.criterion = criterion or torch.nn.BCEWithLogitsLoss()
-        self.flat = FlatGradients(model.parameters(), compress_bf16=compress_bf16)
+        self.accum = max(int(accumulation_steps), 1)
+        self.lr_scheduler, self.group = lr_scheduler, group
+        self.split = bool(overlap) and forward_fn is None and hasattr(model, 'cross_blocks')
+        self.flat = FlatGradients(model.parameters(), compress_bf16=compress_bf16,
+                                  early=_decoder_only_parameters(model) if self.split else None)
         if hasattr(model, 'direct_param_grads') or hasattr(model, 'runtime'):
             model.direct_param_grads = True     # HIP model: weight-gradient kernels add straight into the flat buffer
         self.forward_fn = forward_fn or (lambda m, x: m(x))
         self.use_graph = use_graph and torch.cuda.is_available()
-        self._g_fb = self._g_opt = None
+        self.hip_opt = hasattr(optimizer, 'bind_flat')       # optim.FlatAdamW: clip + AdamW + shadow refresh in one kernel
+        if self.hip_opt:
+            optimizer.bind_flat(self.flat, model)
+        elif self.use_graph:
+            bad = [g for g in optimizer.param_groups if not g.get('capturable', False)]
+            if bad:
+                raise ValueError('TrainStep(use_graph=True) captures optimizer.step() into a hipGraph: build the torch optimizer with '
+                                 'capturable=True (engine.build_optimizer(config, model, capturable=True)) or use optim.FlatAdamW')
+        self._g1 = self._g2 = self._g_opt = None
         self._static_x = self._static_y = self._static_loss = self._static_norm = None
         self._eager_steps = 0
+        self._micro = 0
+        self.num_updates = 0
+        self.last_norm = None
+        self._lr_tensors = None
         self.device_type = 'cuda' if next(model.parameters()).is_cuda else 'cpu'
 
+    # -- learning rate -----------------------------------------------------------------------
+    def set_lr(self, lr: float, group_index: int | None = None):
+        """Per-iteration LR (misc/engine.py:228 ``lr_scheduler.step_update``): takes effect in eager and replayed updates."""
+        for i, g in enumerate(self.optimizer.param_groups):
+            if group_index is None or i == group_index:
+                g['lr'] = float(lr) * g.get('lr_scale', 1.0)
+        self._sync_lr()
+
+    def _sync_lr(self):
+        """Schedulers write Python floats into ``param_groups[i]['lr']``; a captured update reads a device scalar.
+        Fold the floats into the per-group device tensors (torch optimizers: the tensors ARE ``group['lr']``)."""
+        if self.hip_opt:
+            self.optimizer.sync_hyperparameters()
+            return
+        if not self.use_graph:
+            return
+        if self._lr_tensors is None:
+            dev = next(self.model.parameters()).device
+            self._lr_tensors = [torch.tensor(float(g['lr']), dtype=torch.float32, device=dev) for g in self.optimizer.param_groups]
+        for g, t in zip(self.optimizer.param_groups, self._lr_tensors):
+            if g['lr'] is not t:
+                t.fill_(float(g['lr']))
+                g['lr'] = t
+
     # -- pieces ------------------------------------------------------------------------------
+    def _loss(self, out, y):
+        loss = self.criterion(out.float(), y)
+        return loss / self.accum if self.accum > 1 else loss
+
     def _fwd_bwd(self, x, y):
+        """One-stage form (any model / forward_fn)."""
         with torch.autocast(self.device_type, dtype=torch.bfloat16, enabled=self.amp):
             out = self.forward_fn(self.model, x)
-            loss = self.criterion(out.float(), y)
+            loss = self._loss(out, y)
         loss.backward()
         return loss.detach()
 
+    def _fwd_dec_bwd(self, x, y):
+        """Stage 1 of the split backward: encoder forward, decoder + head forward, loss, decoder backward.
+        Returns (loss, features, d loss / d features)."""
+        with torch.autocast(self.device_type, dtype=torch.bfloat16, enabled=self.amp):
+            feats = self.model(x[:, 0], forward_first_part=True)
+            leaf = feats.detach().requires_grad_(True)
+            out = self.model(leaf, x[:, 1])
+            loss = self._loss(out, y)
+        loss.backward()
+        return loss.detach(), feats, leaf.grad
+
+    @staticmethod
+    def _enc_bwd(feats, dfeats):
+        feats.backward(dfeats)
+
     def _update(self):
-        norm = self.flat.clip_(self.clip_grad) if self.clip_grad is not None else torch.linalg.vector_norm(self.flat.flat)
-        self.optimizer.step()
+        if self.hip_opt:
+            norm = self.optimizer.step_flat(self.clip_grad)      # clip + AdamW + shadow refresh + zero: one pass
+        else:
+            norm = self.flat.clip_(self.clip_grad) if self.clip_grad is not None else torch.linalg.vector_norm(self.flat.flat)
+            self.optimizer.step()
+            self._refresh_shadows()       # the bf16 weight shadows follow the update (eval right after training sees them)
+            self.flat.zero()
         return norm
 
     def _refresh_shadows(self):
@@ -200,46 +374,87 @@ class TrainStep:
             for rt in rts.values():
                 rt.refresh_shadows(params)
 
+    def _after_update(self):
+        self.num_updates += 1
+        if self.lr_scheduler is not None:
+            self.lr_scheduler.step_update(self.num_updates)
+
     # -- public ------------------------------------------------------------------------------
     def step(self, x, y):
-        if not self.use_graph:
-            self.flat.zero()
-            loss = self._fwd_bwd(x, y)
-            self.flat.all_reduce_mean()
-            self.last_norm = self._update()
-            return loss
-        if self._g_fb is None:
-            if self._eager_steps < 2:      # warm up allocator, workspaces and weight shadows eagerly
+        """One call of the loop body.  Returns the (micro-batch) loss; ``last_norm`` holds the gradient norm of the
+        last update."""
+        last = (self._micro + 1) % self.accum == 0
+        self._micro += 1
+        if self.use_graph and self._g1 is None and self._eager_steps >= 2 * self.accum and (self._micro - 1) % self.accum == 0:
+            self._capture(x, y)     # at the start of an accumulation cycle, after two eager updates: the flat buffer is zero
+        if self._g1 is None:
+            if self.use_graph:             # warm up allocator, workspaces and weight shadows eagerly
                 self._eager_steps += 1
-                self.flat.zero()
-                loss = self._fwd_bwd(x, y)
-                self.flat.all_reduce_mean()
-                self.last_norm = self._update()
-                return loss
-            self._capture(x, y)
+            return self._eager(x, y, last)
         self._static_x.copy_(x, non_blocking=True)
         self._static_y.copy_(y, non_blocking=True)
-        self._g_fb.replay()
-        self.flat.all_reduce_mean()
-        self._g_opt.replay()
-        self.last_norm = self._static_norm
+        buckets = self.flat.buckets()
+        self._g1.replay()
+        if self._g2 is not None:
+            if last and len(buckets) == 2:
+                self.flat.start_all_reduce(*buckets[0], group=self.group)   # runs under the encoder's backward
+            self._g2.replay()
+        if last:
+            if self._g2 is not None and len(buckets) == 2:
+                self.flat.start_all_reduce(*buckets[1], group=self.group)
+            else:
+                self.flat.start_all_reduce(0, self.flat.flat.numel(), group=self.group)
+            self.flat.finish_all_reduce()
+            self._sync_lr()
+            self._g_opt.replay()
+            self.last_norm = self._static_norm
+            self._after_update()
         return self._static_loss
 
+    def _eager(self, x, y, last):
+        buckets = self.flat.buckets()
+        if self.split and x.dim() == 5:
+            loss, feats, dfeats = self._fwd_dec_bwd(x, y)
+            if last and len(buckets) == 2:
+                self.flat.start_all_reduce(*buckets[0], group=self.group)
+            self._enc_bwd(feats, dfeats)
+            if last:
+                if len(buckets) == 2:
+                    self.flat.start_all_reduce(*buckets[1], group=self.group)
+                else:
+                    self.flat.start_all_reduce(0, self.flat.flat.numel(), group=self.group)
+        else:
+            loss = self._fwd_bwd(x, y)
+            if last:
+                self.flat.start_all_reduce(0, self.flat.flat.numel(), group=self.group)
+        if last:
+            self.flat.finish_all_reduce()
+            self._sync_lr()
+            self.last_norm = self._update()
+            self._after_update()
+        return loss
+
     def _capture(self, x, y):
+        from . import ops
         self._static_x, self._static_y = x.clone(), y.clone()
+        self._sync_lr()
         torch.cuda.synchronize()
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            self._refresh_shadows()
-        torch.cuda.current_stream().wait_stream(side)
-        self._g_fb = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._g_fb):
-            self._refresh_shadows()           # weights changed since the last replay: recast in place
-            self.flat.zero()
-            self._static_loss = self._fwd_bwd(self._static_x, self._static_y)
+        ops.pin_workspace()               # captured kernels bake buffer addresses in: later growth must not free them
+        for rt in getattr(self.model, '_runtimes', {}).values():
+            rt.pinned = True
+        split = self.split and x.dim() == 5
+        self._g1 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._g1):
+            if split:
+                self._static_loss, self._feats, self._dfeats = self._fwd_dec_bwd(self._static_x, self._static_y)
+            else:
+                self._static_loss = self._fwd_bwd(self._static_x, self._static_y)
+        if split:
+            self._g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._g2, pool=self._g1.pool()):
+                self._enc_bwd(self._feats, self._dfeats)
         self._g_opt = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._g_opt, pool=self._g_fb.pool()):
+        with torch.cuda.graph(self._g_opt, pool=self._g1.pool()):
             self._static_norm = self._update()
 
 

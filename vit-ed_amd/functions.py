@@ -47,6 +47,8 @@ class Runtime:
         self.scale = self.head_dim ** -0.5
         self.act_dtype = act_dtype
         self.direct_grads = False   # accumulate parameter gradients straight into existing p.grad (engine.FlatGradients)
+        self.pinned = False         # a captured hipGraph reads the shadow buffers: never free one, only refresh in place
+        self._retired = []
         self._shadow = {}
 
     @property
@@ -76,9 +78,16 @@ class Runtime:
                 # refresh IN PLACE: a captured graph keeps reading the same shadow buffer
                 ent = (w._version, w.data_ptr(), make(ent[2]))
             else:
+                if ent is not None and self.pinned:
+                    self._retired.append(ent[2])     # the graph still reads the old buffer: keep it alive
                 ent = (w._version, w.data_ptr(), make())
             self._shadow[key] = ent
         return ent[2]
+
+    def mark_shadows_current(self):
+        """The optimizer kernel rewrote parameters and shadows together (optim.FlatAdamW): nothing to recast."""
+        # entries are keyed by (id(param), tag) and validated by (version, data_ptr); a raw kernel write bumps neither
+        return None
 
     def refresh_shadows(self, params):
         """Recast every cached shadow in place with ONE multi-tensor launch (call after an optimizer step when
@@ -240,10 +249,6 @@ def _patch_tokens_bwd(rt, dx, patches, pw, pb, pos, with_cls, batch):
     return dw, db, dpos, dcls
 
 
-def _bias(b):
-    return b
-
-
 # ---------------------------------------------------------------------------------------------
 # encoder: forward_first_part (vision_transformer.py:382-388)
 # ---------------------------------------------------------------------------------------------
@@ -254,7 +259,7 @@ class EncoderFn(torch.autograd.Function):
         nb = len(ENC_BLOCK_KEYS)
         blocks = [params[3 + i * nb: 3 + (i + 1) * nb] for i in range(rt.depth)]
         grad = any(ctx.needs_input_grad)  # False under no_grad: nothing is saved for inference
-        x, patches, batch, n = _patch_tokens_fwd(rt, img, pw, _bias(pb), pos, with_cls=False)
+        x, patches, batch, n = _patch_tokens_fwd(rt, img, pw, pb, pos, with_cls=False)
         tape = []
         for P in blocks:
             g1, b1, wqkv, bqkv, wproj, bproj, g2, b2, w1, bb1, w2, bb2 = P
@@ -302,7 +307,7 @@ class DecoderFn(torch.autograd.Function):
         nb = len(DEC_BLOCK_KEYS)
         blocks = [params[ns + i * nb: ns + (i + 1) * nb] for i in range(rt.c_depth)]
         grad = any(ctx.needs_input_grad)
-        x, patches, batch, n = _patch_tokens_fwd(rt, img2, pw, _bias(pb), pos, with_cls=True, cls=cls, batch_index=img2_index)
+        x, patches, batch, n = _patch_tokens_fwd(rt, img2, pw, pb, pos, with_cls=True, cls=cls, batch_index=img2_index)
         assert feats.shape == (batch, rt.n1, rt.dim), f'features {tuple(feats.shape)} do not match {batch} image-2 samples'
         ctxf = feats.detach().contiguous().float().view(batch * rt.n1, rt.dim)
         tape = []
@@ -326,7 +331,7 @@ class DecoderFn(torch.autograd.Function):
         # final norm on the cls rows only (LayerNorm is row-wise; only x[:, 0] reaches the head, :400,:417)
         x3 = x.view(batch, n, d)
         y, mN, rN = ops.layernorm_fwd(x3[:, 0, :], gN, bN, LN_EPS, rt.act_dtype)
-        logits = ops.gemm(y, rt.weight(wh), epilogue=EPI_STORE_F32, bias=_bias(bh))
+        logits = ops.gemm(y, rt.weight(wh), epilogue=EPI_STORE_F32, bias=bh)
         if grad:
             ctx.rt, ctx.tape, ctx.patches, ctx.batch, ctx.params = rt, tape, patches, batch, params
             ctx.ctxf, ctx.final = ctxf, (x, y, mN, rN)

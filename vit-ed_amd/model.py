@@ -145,6 +145,13 @@ class VisionTransformerCustom(nn.Module):
             raise AssertionError('dim should be divisible by num_heads')
         if img_size % patch_size:
             raise AssertionError('image size must be a multiple of the patch size')
+        # limits of the HIP kernels (they would return VITED_ERR_UNSUPPORTED at the first launch): say so here
+        if embed_dim % 4 or embed_dim > 1024:
+            raise NotImplementedError(f'EMBED_DIM={embed_dim}: the LayerNorm kernels cover multiples of 4 up to 1024 '
+                                      '(csrc/layernorm.hip, LN_MAX_VPL)')
+        if embed_dim // num_heads not in (32, 64):
+            raise NotImplementedError(f'head_dim={embed_dim // num_heads}: the attention kernels cover head_dim 32 and 64 '
+                                      '(12 x 32 at configs/puzzle, 6 x 64 at configs/hisfrag)')
         self.img_size, self.patch_size, self.in_chans = img_size, patch_size, in_chans
         self.num_classes, self.embed_dim = num_classes, embed_dim
         self.num_features = embed_dim

@@ -46,6 +46,15 @@ def _rows2d(t: torch.Tensor):
 
 
 _ws_cache = {}
+_ws_pinned = False
+_ws_retired = []
+
+
+def pin_workspace():
+    """Called when a hipGraph has been captured: its kernels baked the workspace address in, so a later (eager) growth
+    must not free that buffer - it is retired (kept alive) and a larger one serves the eager calls."""
+    global _ws_pinned
+    _ws_pinned = True
 
 
 def workspace(nbytes: int, device) -> torch.Tensor:
@@ -56,6 +65,8 @@ def workspace(nbytes: int, device) -> torch.Tensor:
     if buf is None or buf.numel() < n:
         if torch.cuda.is_current_stream_capturing():
             raise RuntimeError('vited workspace must be sized before graph capture: run one eager step first')
+        if buf is not None and _ws_pinned:
+            _ws_retired.append(buf)
         buf = torch.empty(max(n, 1 << 20), dtype=torch.float32, device=device)
         _ws_cache[key] = buf
     return buf
