@@ -1,33 +1,46 @@
 #!/usr/bin/env python3
-"""Headline benchmark: patch-pairs/sec of one ViT-ED training step (forward + backward [+ RCCL
-gradient all-reduce] + clip + AdamW) on synthetic 64x64 patch pairs, config A
-(configs/puzzle/div2k_erosion7_4bin_patch8_64.yaml), batch 1024 per GPU, bf16 MFMA path.
+"""Headline benchmark: patch-pairs/sec of one ViT-ED training step (forward + backward [+ RCCL gradient all-reduce] +
+clip + AdamW) on synthetic patch pairs, bf16 MFMA path.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload A-train|H-train|H-infer]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+``--gpus N`` with no WORLD_SIZE in the environment starts the N ranks itself (``torch.distributed.run`` as a child; this
+parent makes no GPU call) and relays rank 0's JSON line; under an external launcher WORLD_SIZE must equal ``--gpus``.
+
+Workloads (BASELINE.json ``configs``):
+  A-train  configs/puzzle/div2k_erosion7_4bin_patch8_64.yaml, 1024 pairs/GPU, full train step (the headline, default)
+  H-train  configs/hisfrag/hisfrag20_patch16_512.yaml, 24 images/GPU: the two-stage step of hisfrag.py:117-159 (encoder once
+           per image, 24 positive + 48 negative pairs through the decoder, one backward), 72 pairs/step
+  H-infer  the same model, pairwise similarity-matrix inference (hisfrag.py:161-302): 96 images/GPU, pair batch 512
 
 One JSON line on rank 0 (contract in the task statement).  Extra objects:
-  roofline      dominant kernel class (by summed device time), timed live with HIP events on the
-                launch stream during an instrumented pass of the same step; achieved = algorithmic
-                FLOPs of those launches / their summed duration; peak = 2500 TFLOP/s dense bf16.
-  cpu_baseline  the fp32 CPU oracle (oracle/vited_oracle.py, a port - the reference itself cannot
-                travel) on a bounded sample: config A, batch 32, fwd+bwd, median of 5 steps.
+  roofline      dominant kernel class (by summed device time), timed live with HIP events on the launch stream during an
+                instrumented eager pass of the same step; achieved = algorithmic FLOPs of those launches / their summed
+                duration; peak = 2500 TFLOP/s dense bf16 (MI355X_MICROARCH.md), with the peak derived from this box's
+                rocminfo (CUs x 4 SIMD x 1024 FLOP/clk x max clock) recorded beside it.
+  cpu_baseline  the fp32 CPU oracle (oracle/vited_oracle.py, a port - the reference itself cannot travel) on a bounded
+                sample: config A, batch 32, fwd+bwd, median of 5 steps, with the host's CPU model and thread count.
 """
 import argparse
+import contextlib
 import json
+import math
 import os
+import re
 import statistics
+import subprocess
 import sys
 import time
-
-import torch
-import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_DENSE_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PF dense bf16 (never the 2:1-sparse figure)
+CFG_A = os.path.join(ROOT, 'configs', 'puzzle', 'div2k_erosion7_4bin_patch8_64.yaml')
+CFG_H = os.path.join(ROOT, 'configs', 'hisfrag', 'hisfrag20_patch16_512.yaml')
+PMC_TRAFFIC_CSV = os.path.join(ROOT, 'profiles', 'r02_hbm_traffic_per_kernel.csv')
 
 
 def parse():
@@ -35,18 +48,81 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=1024, help='pairs per GPU')
-    ap.add_argument('--cfg', default=os.path.join(ROOT, 'configs', 'puzzle', 'div2k_erosion7_4bin_patch8_64.yaml'))
+    ap.add_argument('--workload', default='A-train', choices=['A-train', 'H-train', 'H-infer'])
+    ap.add_argument('--batch', type=int, default=None, help='pairs (A-train) or images (H-*) per GPU; default 1024 / 24 / 96')
+    ap.add_argument('--cfg', default=None, help='override the YAML of the workload')
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying hipGraphs')
     ap.add_argument('--fp32', action='store_true', help='run the exact fp32 kernels (parity path; not the headline)')
+    ap.add_argument('--torch-optim', action='store_true', help='torch.optim.AdamW(fused) + separate clip instead of the HIP optimizer kernel')
+    ap.add_argument('--no-overlap', action='store_true', help='one all-reduce after the whole backward instead of two buckets')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--compress-bf16', action='store_true', help='bf16 gradients on the wire')
     return ap.parse_args()
 
 
+# ---------------------------------------------------------------------------------------------
+# launcher: --gpus N without a launcher -> start the N ranks (no GPU call in this process)
+# ---------------------------------------------------------------------------------------------
+def spawn_ranks(args):
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith('{') and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0 or line is None:
+        raise SystemExit(f'bench.py --gpus {args.gpus}: the launched ranks failed (exit code {proc.returncode})')
+    if json.loads(line)['n_gpus'] != args.gpus:
+        raise SystemExit(f'bench.py --gpus {args.gpus}: the job ran on {json.loads(line)["n_gpus"]} ranks')
+    print(line, flush=True)
+
+
+# ---------------------------------------------------------------------------------------------
+# host facts
+# ---------------------------------------------------------------------------------------------
+def cpu_model_name():
+    try:
+        for ln in open('/proc/cpuinfo'):
+            if ln.lower().startswith('model name'):
+                return ln.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def rocminfo_peak():
+    """Dense bf16 MFMA peak of THIS device from rocminfo: CUs x 4 SIMDs x 1024 FLOP/clk/SIMD (one 16x16x32 bf16 MFMA = 16,384
+    FLOP per 16 cycles) x max clock.  None when rocminfo is unavailable.  (A child process: it does not touch this process's HIP state.)"""
+    try:
+        txt = subprocess.run(['rocminfo'], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=60).stdout
+    except (OSError, subprocess.SubprocessError):
+        return None
+    for agent in txt.split('*******')[1:]:
+        if 'gfx' not in agent or 'Device Type:             GPU' not in agent:
+            continue
+        cu = re.search(r'Compute Unit:\s+(\d+)', agent)
+        clk = re.search(r'Max Clock Freq\. \(MHz\):\s+(\d+)', agent)
+        name = re.search(r'Name:\s+(gfx\w+)', agent)
+        if cu and clk:
+            cus, mhz = int(cu.group(1)), int(clk.group(1))
+            return {'cus': cus, 'max_clock_mhz': mhz, 'arch': name.group(1) if name else '?',
+                    'tflops': round(cus * 4 * 1024 * mhz * 1e6 / 1e12, 1)}
+    return None
+
+
 def cpu_baseline(cfg_shape, seconds_budget=40.0):
     """fp32 eager PyTorch oracle on the host cores: batch 32, fwd+bwd."""
+    import torch
     from oracle import vited_oracle as vo
     cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
@@ -68,11 +144,12 @@ def cpu_baseline(cfg_shape, seconds_budget=40.0):
         if time.time() - t_start > seconds_budget and len(times) >= 2:
             break
     med = statistics.median(times)
-    return {'value': round(b / med, 2), 'unit': 'pairs/s', 'cores': cores, 'kind': 'port',
-            'sample': f'config A, batch {b}, fp32 eager CPU oracle, fwd+bwd, median of {len(times)} steps after 2 warm-ups'}
+    return {'value': round(b / med, 2), 'unit': 'pairs/s', 'cores': cores, 'kind': 'port', 'cpu': cpu_model_name(),
+            'sample': f'config A, batch {b}, fp32 eager CPU oracle, fwd+bwd, median of {len(times)} steps after 2 warm-ups, '
+                      f'torch.set_num_threads({cores})'}
 
 
-def pmc_traffic(kernel_class, path=os.path.join(ROOT, 'profiles', 'r01_hbm_traffic_per_kernel.csv')):
+def pmc_traffic(kernel_class, path=PMC_TRAFFIC_CSV):
     """HBM bytes per launch of the dominant kernel class from the COMMITTED rocprofv3 PMC summary (FETCH_SIZE / WRITE_SIZE
     passes cannot run inside this process; profiles/collect.sh + summarize.py regenerate the file): launch-weighted
     mean over the class's template instances.  None when the file or the class is missing."""
@@ -86,7 +163,7 @@ def pmc_traffic(kernel_class, path=os.path.join(ROOT, 'profiles', 'r01_hbm_traff
                 tot += float(launches) * float(total)
                 n += float(launches)
         if n:
-            return {'traffic': round(tot / n * 1e6), 'traffic_unit': 'bytes/launch (rocprofv3 PMC, profiles/r01_hbm_traffic_per_kernel.csv)'}
+            return {'traffic': round(tot / n * 1e6), 'traffic_unit': f'bytes/launch (rocprofv3 PMC, profiles/{os.path.basename(path)})'}
     except (OSError, ValueError):
         pass
     return {'traffic': None}
@@ -96,12 +173,14 @@ class LaunchTimer:
     """Brackets every C-ABI contraction launch with HIP events on the launch stream."""
 
     def __init__(self, ops):
-        self.ops, self.records = ops, []
+        import torch
+        self.torch, self.ops, self.records = torch, ops, []
         self._orig = {}
 
     def _wrap(self, name, flops_fn, label_fn, bytes_fn=None):
         orig = getattr(self.ops, name)
         self._orig[name] = orig
+        torch = self.torch
 
         def wrapped(*a, **k):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -125,7 +204,7 @@ class LaunchTimer:
             n = B.shape[0] if k.get('b_layout', 0) == 0 else B.shape[1]
             es = A.element_size()
             epi = k.get('epilogue', 0)
-            out = {0: es, 1: 2 * es, 2: 4 + 4, 3: es + es, 4: 4}.get(epi, es)   # store | z+gelu | residual in + fp32 out | aux in + out | fp32
+            out = {0: es, 1: 2 * es, 2: 4 + 4, 3: es + es, 4: 4}.get(epi, es)   # store | two outputs | residual in + fp32 out | aux in + out | fp32
             return float(m * kk * es + n * kk * es + m * n * out)
 
         def tn_flops(a, k):
@@ -140,6 +219,8 @@ class LaunchTimer:
         self._wrap('linear_bwd_weight', tn_flops, lambda a, k, gp, ap: 'gemm_tn_mfma_kernel(+slab/bias sums)' if gp == 2 else 'gemm_tn_portable_kernel')
         self._wrap('attention_fwd', attn_fwd_flops, lambda a, k, gp, ap: 'attn_fwd_mfma' if ap == 2 else 'attn_fwd_portable_kernel')
         self._wrap('attention_bwd', lambda a, k: 2.5 * attn_fwd_flops(a, k), lambda a, k, gp, ap: 'attn_bwd_mfma' if ap == 2 else 'attn_bwd_portable_kernels')
+        if hasattr(self.ops, 'mlp_fwd'):
+            self._wrap('mlp_fwd', lambda a, k: 4.0 * a[0].shape[0] * a[0].shape[1] * a[3].shape[0], lambda a, k, gp, ap: 'mlp_fwd_fused_kernel')
         return self
 
     def __exit__(self, *exc):
@@ -147,7 +228,7 @@ class LaunchTimer:
             setattr(self.ops, name, orig)
 
     def summary(self):
-        torch.cuda.synchronize()
+        self.torch.cuda.synchronize()
         agg = {}
         for label, fl, e0, e1, nbytes in self.records:
             ms = e0.elapsed_time(e1)
@@ -159,11 +240,41 @@ class LaunchTimer:
         return agg
 
 
+def roofline_of(V, run_once, passes=2):
+    """Instrumented eager passes of ``run_once`` -> the ``roofline`` / ``kernels`` objects of the JSON line."""
+    run_once()                           # eager warm-up: sizes workspaces, builds weight shadows
+    with LaunchTimer(V.ops) as lt:       # same work, launched eagerly so each launch can be bracketed
+        for _ in range(passes):
+            run_once()
+        agg = lt.summary()
+    kernels = {k: {'launches': v['launches'], 'avg_us': round(1e3 * v['ms'] / v['launches'], 2),
+                   'total_ms_per_step': round(v['ms'] / passes, 3), 'tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 1)}
+               for k, v in sorted(agg.items(), key=lambda kv: -kv[1]['ms'])}
+    dom = next(iter(kernels))
+    d = agg[dom]
+    achieved = d['flops'] / (d['ms'] * 1e-3) / 1e12
+    derived = rocminfo_peak()
+    roof = {'bound': 'mfma', 'kernel': dom, 'achieved': round(achieved, 1), 'peak': PEAK_BF16_DENSE_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': round(achieved / PEAK_BF16_DENSE_TFLOPS, 4), 'peak_from_rocminfo': derived,
+            'avg_launch_us': round(1e3 * d['ms'] / d['launches'], 2), 'launches_per_step': d['launches'] // passes,
+            'algorithmic_bytes_per_launch': round(d['bytes'] / d['launches']), **pmc_traffic(dom)}
+    return {'roofline': roof, 'kernels': kernels}
+
+
+# ---------------------------------------------------------------------------------------------
 def main():
     args = parse()
-    world = int(os.environ.get('WORLD_SIZE', 1))
+    env_world = os.environ.get('WORLD_SIZE')
+    if env_world is None and args.gpus > 1:
+        return spawn_ranks(args)                  # before anything touches the GPU
+    world = int(env_world or 1)
+    if world != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks')
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
+
+    import torch
+    import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit('bench.py measures the MI355X HIP path; no GPU is visible (the CPU oracle is only the baseline leg)')
     # rehearsal knobs (a 1-GPU box cannot run 2 RCCL ranks): VITED_DIST_BACKEND=gloo VITED_FORCE_DEVICE=0
@@ -178,92 +289,149 @@ def main():
     from vited_amd import engine
     V._lib.load()
 
-    import contextlib
+    cfg_path = args.cfg or (CFG_A if args.workload == 'A-train' else CFG_H)
     with contextlib.redirect_stdout(sys.stderr):   # the reference's loaders print; stdout carries only the JSON line
-        cfg = V.config_from_yaml(args.cfg)
+        cfg = V.config_from_yaml(cfg_path)
         torch.manual_seed(cfg.SEED + rank)          # misc/engine.py:28
         model = V.build_model(cfg).to(dev)
     model.compute_dtype = torch.float32 if args.fp32 else torch.bfloat16
-    flops_per_pair = 3 * model.flops()          # fwd+bwd = 3 x fwd (13,299,397,632 at config A)
     engine.broadcast_parameters(model)
-    B, S, C = args.batch, cfg.DATA.IMG_SIZE, cfg.MODEL.NUM_CLASSES
-    x = torch.randn(B, 2, 3, S, S, device=dev).clamp_(-1, 1)
-    y = (torch.rand(B, C, device=dev) > 0.75).float()
+    S, C = cfg.DATA.IMG_SIZE, cfg.MODEL.NUM_CLASSES
+    name = cfg.MODEL.NAME
+    enc_flops, dec_flops = model.flops_parts()     # per image / per pair, forward
     use_graph = not args.no_graph
-    lr = 1e-4 * B * world / 256.0                # linear LR scaling, misc/engine.py:33-36
-    groups = engine.param_groups_no_decay_1d(model)
-    opt = torch.optim.AdamW(groups, lr=lr, weight_decay=0.05, eps=1e-8, betas=(0.9, 0.999), fused=True, capturable=use_graph)
-    step = engine.TrainStep(model, opt, clip_grad=5.0, amp=not args.fp32, use_graph=use_graph, compress_bf16=args.compress_bf16)
-
-    roof = None
-    if rank == 0 and not args.no_roofline:
-        step.flat.zero()
-        step._fwd_bwd(x, y)                  # eager warm-up: sizes workspaces, builds weight shadows (no collective, no update)
-        with LaunchTimer(V.ops) as lt:       # same step, launched eagerly so each launch can be bracketed
-            for _ in range(2):
-                step.flat.zero()
-                step._fwd_bwd(x, y)
-            agg = lt.summary()
-        kernels = {k: {'launches': v['launches'], 'avg_us': round(1e3 * v['ms'] / v['launches'], 2),
-                       'total_ms_per_step': round(v['ms'] / 2, 3), 'tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 1)}
-                   for k, v in sorted(agg.items(), key=lambda kv: -kv[1]['ms'])}
-        dom = next(iter(kernels))
-        d = agg[dom]
-        achieved = d['flops'] / (d['ms'] * 1e-3) / 1e12
-        roof = {'roofline': {'bound': 'mfma', 'kernel': dom, 'achieved': round(achieved, 1), 'peak': PEAK_BF16_DENSE_TFLOPS,
-                             'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_BF16_DENSE_TFLOPS, 4),
-                             'avg_launch_us': round(1e3 * d['ms'] / d['launches'], 2), 'launches_per_step': d['launches'] // 2,
-                             'algorithmic_bytes_per_launch': round(d['bytes'] / d['launches']), **pmc_traffic(dom)},
-                'kernels': kernels}
-        step.flat.zero()
-    if world > 1:
-        dist.barrier()
-    # setup (eager steps + graph capture) and W warm-up steps, all untimed
-    for _ in range(3 if use_graph else 1):
-        step.step(x, y)
-    for _ in range(args.warmup):
-        step.step(x, y)
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step.step(x, y)
-    fence()
-    elapsed = time.perf_counter() - t0
+    extra = {}
+    if args.workload in ('A-train', 'H-train'):
+        B = args.batch or (1024 if args.workload == 'A-train' else 24)
+        lr = 1e-4 * B * world / 256.0                # linear LR scaling, misc/engine.py:33-36
+        groups = engine.param_groups_no_decay_1d(model)
+        okw = dict(lr=lr, weight_decay=0.05, eps=1e-8, betas=(0.9, 0.999))
+        if args.torch_optim:
+            opt = torch.optim.AdamW(groups, fused=True, capturable=use_graph, **okw)
+        else:
+            opt = V.optim.FlatAdamW(groups, **okw)
+        if args.workload == 'A-train':
+            x = torch.randn(B, 2, 3, S, S, device=dev).clamp_(-1, 1)
+            y = (torch.rand(B, C, device=dev) > 0.75).float()
+            step = engine.TrainStep(model, opt, clip_grad=5.0, amp=not args.fp32, use_graph=use_graph, compress_bf16=args.compress_bf16,
+                                    overlap=not args.no_overlap)
+            units, unit_flops = B, 3 * (enc_flops + dec_flops)     # fwd+bwd = 3 x fwd (13,299,397,632 at config A)
+            what = f'{os.path.basename(cfg_path)} batch {B}/GPU, {S}x{S} random patch pairs, full train step'
+        else:
+            # hisfrag.py:117-159 with MPerClassSampler(m=3): 8 writers x 3 images -> 24 positive pairs + min(252, 2*24) = 48 negatives
+            use_graph = False                        # the pair batch is a structured input; ~100 ms of kernels hide the launches
+            samples = torch.randn(B, 3, S, S, device=dev).clamp_(-1, 1)
+            targets = torch.arange(B // 3, device=dev).repeat_interleave(3)
+            groups_idx, labels = engine.mine_pairs(targets, generator=torch.Generator(device=dev).manual_seed(cfg.SEED + rank))
+            P = int(groups_idx.shape[0])
+
+            def two_stage(m, batch):
+                imgs, pairs = batch
+                feats = m(imgs, forward_first_part=True)
+                return m(feats[pairs[:, 1]], imgs[pairs[:, 0]])
+
+            x, y = (samples, groups_idx), labels
+            step = engine.TrainStep(model, opt, clip_grad=5.0, amp=not args.fp32, use_graph=False, compress_bf16=args.compress_bf16,
+                                    forward_fn=two_stage)
+            units, unit_flops = P, 3 * (enc_flops * B + dec_flops * P) / P
+            what = (f'{os.path.basename(cfg_path)} {B} images/GPU ({S}x{S}), two-stage step of hisfrag.py:117-159: encoder once per image, '
+                    f'{P} mined pairs through the decoder, one backward')
+            extra['images_per_step'] = B * world
+
+        roof = None
+        if rank == 0 and not args.no_roofline:
+            def run_once():
+                step.flat.zero()
+                step._fwd_bwd(x, y)              # no collective, no update
+            roof = roofline_of(V, run_once)
+            step.flat.zero()
+        if world > 1:
+            dist.barrier()
+        # setup (eager steps + graph capture) and W warm-up steps, all untimed
+        loss_first = float(step.step(x, y))
+        for _ in range(2 if use_graph else 0):
+            step.step(x, y)
+        for _ in range(args.warmup):
+            step.step(x, y)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = step.step(x, y)
+        fence()
+        elapsed = time.perf_counter() - t0
+        loss_val, norm_val = float(loss), float(step.last_norm)
+        # training on one fixed batch must reduce its loss; anything else means the step is not doing its work
+        if not (math.isfinite(loss_val) and math.isfinite(norm_val) and loss_val < loss_first):
+            raise SystemExit(f'bench.py: the timed steps did not train (loss {loss_first:.5f} -> {loss_val:.5f}, grad norm {norm_val})')
+        extra.update({'loss_first': round(loss_first, 5), 'loss': round(loss_val, 5), 'grad_norm': round(norm_val, 5),
+                      'optimizer': 'torch.optim.AdamW(fused)' if args.torch_optim else 'vited_adamw_step (HIP, fused clip)'})
+        metric = f'patch-pairs/sec fwd+bwd, {name} ViT-ED'
+        what += f' (fwd+bwd+{"RCCL all-reduce+" if world > 1 else ""}clip+AdamW)'
+    else:
+        # pairwise similarity-matrix inference (hisfrag.py:161-302): every rank encodes its row block and streams all later images
+        n_img = (args.batch or 96) * world
+        g = torch.Generator(device=dev).manual_seed(cfg.SEED)
+        images = torch.randn(n_img, 3, S, S, device=dev, generator=g).clamp_(-1, 1)
+        pair_batch = 512                              # README.md:63 (--opts DATA.TEST_BATCH_SIZE 512), BASELINE config 5
+        bounds = engine.shard_rows_by_pair_count(n_img, world)
+        my_rows = bounds[rank + 1] - bounds[rank]
+        my_pairs = sum(n_img - i for i in range(bounds[rank], bounds[rank + 1]))
+        total_pairs = n_img * (n_img + 1) // 2
+
+        def run():
+            return engine.pairwise_similarity(model, images, rank=rank, world=world, block=64, pair_batch=pair_batch, amp=not args.fp32)
+
+        roof = None
+        if rank == 0 and not args.no_roofline and world == 1:
+            small = images[:24]
+            roof = roofline_of(V, lambda: engine.pairwise_similarity(model, small, block=24, pair_batch=pair_batch, amp=not args.fp32), passes=1)
+        for _ in range(max(args.warmup, 1) if args.warmup else 1):
+            run()
+        args.steps = max(1, min(args.steps, 5))      # one "step" = one whole similarity matrix
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            sim = run()
+        fence()
+        elapsed = time.perf_counter() - t0
+        if not bool(torch.isfinite(sim.float()).all()) or not torch.equal(sim, sim.t()):
+            raise SystemExit('bench.py: the similarity matrix is not finite / symmetric')
+        units = total_pairs / world                   # value below multiplies by world again
+        unit_flops = (dec_flops * total_pairs + enc_flops * n_img) / total_pairs
+        metric = f'pairs/sec similarity-matrix inference, {name} ViT-ED'
+        what = (f'{os.path.basename(cfg_path)} {n_img} images ({S}x{S}) -> {total_pairs} pairs (upper triangle incl. diagonal), pair batch '
+                f'{pair_batch}, encoder once per image, row blocks sharded by pair count, one all-gather of scores')
+        extra.update({'pairs_this_rank': my_pairs, 'rows_this_rank': my_rows})
+        B = n_img // world
+
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    loss_val = float(loss.item())
     ms_per_step = 1e3 * elapsed / args.steps
-    pairs_per_s = B * world * args.steps / elapsed
-
+    per_s = units * world * args.steps / elapsed
     out = {
-        'metric': 'patch-pairs/sec fwd+bwd, div2k patch8_64 ViT-ED', 'value': round(pairs_per_s, 1), 'unit': 'pairs/s',
+        'metric': metric, 'value': round(per_s, 1), 'unit': 'pairs/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32' if args.fp32 else 'bf16', 'data': 'synthetic',
-        'config': {'workload': f'{os.path.basename(args.cfg)} batch {B}/GPU, {S}x{S} random patch pairs, full train step '
-                               f'(fwd+bwd+{"RCCL all-reduce+" if world > 1 else ""}clip+AdamW)',
-                   'global_batch': B * world, 'parallelism': f'dp{world}', 'hipgraph': use_graph},
-        'step_tflops': round(pairs_per_s * flops_per_pair / 1e12, 2),
-        'step_frac_of_bf16_peak': round(pairs_per_s * flops_per_pair / 1e12 / (PEAK_BF16_DENSE_TFLOPS * world), 4),
-        'loss': round(loss_val, 5),
+        'config': {'workload': what, 'global_batch': B * world, 'parallelism': f'dp{world}', 'hipgraph': use_graph and args.workload == 'A-train'},
+        'step_tflops': round(per_s * unit_flops / 1e12, 2),
+        'step_frac_of_bf16_peak': round(per_s * unit_flops / 1e12 / (PEAK_BF16_DENSE_TFLOPS * world), 4),
+        'flops_per_unit': round(unit_flops),
     }
-
+    out.update(extra)
     if roof is not None:
         out.update(roof)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import vited_oracle as vo
-        pjs = cfg.MODEL.PJS
-        shape = vo.ViTEDShape(img_size=S, patch_size=pjs.PATCH_SIZE, in_chans=pjs.IN_CHANS, num_classes=C,
-                              embed_dim=pjs.EMBED_DIM, depth=pjs.DEPTH, c_depth=pjs.C_DEPTH, num_heads=pjs.NUM_HEADS)
-        out['cpu_baseline'] = cpu_baseline(shape)
+        out['cpu_baseline'] = cpu_baseline(vo.SHAPE_A)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

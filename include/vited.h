@@ -45,6 +45,10 @@ extern "C" {
 #define VITED_EPI_RESIDUAL 2       /* out_f32[orow] = residual[rrow] + acc + bias (row remap below) */
 #define VITED_EPI_MUL_GELU_GRAD 3  /* out = T(acc * gelu_erf'(aux)), aux = saved pre-activation    */
 #define VITED_EPI_STORE_F32 4      /* out_f32 = acc + bias (logits of the head stay fp32)           */
+#define VITED_EPI_MUL 5            /* out = T((acc + bias) * aux), aux = a saved factor (gelu'(z))   */
+#define VITED_EPI_GELU_GRAD 6      /* out = T(gelu_erf'(z)), out2 = T(gelu_erf(z)), z = acc + bias:
+                                      what fc1 saves for backward (timm Mlp: the backward of GELU then is
+                                      one multiply, VITED_EPI_MUL, instead of an erf/exp per element)  */
 
 /* B-operand layouts (vited_gemm) */
 #define VITED_B_NK 0 /* B is [N, K] row-major: out = A . B^T  (nn.Linear weight)                   */
@@ -123,7 +127,7 @@ int vited_layernorm_bwd(const void* dy, int dy_dtype, int64_t dy_ld, const float
 /* acc[m, n] = sum_k A[m, k] * B(n, k), fp32 accumulation; A is `dtype` [M, K] (row stride lda);
  * B is `dtype`, laid out per b_layout (row stride ldb); then the epilogue (VITED_EPI_*):
  *   bias      fp32 [N] or null
- *   aux       `dtype` [M, N] (row stride ldo)        - MUL_GELU_GRAD only
+ *   aux       `dtype` [M, N] (row stride ldo)        - MUL_GELU_GRAD and MUL
  *   residual  fp32                                     - RESIDUAL only
  *   out/out2  `dtype` [M, N] (row stride ldo); for RESIDUAL and STORE_F32 `out` is fp32
  * RESIDUAL row remap (patch-embed writes tokens behind a cls row and adds a broadcast pos_embed):
@@ -142,6 +146,20 @@ int64_t vited_linear_bwd_weight_workspace_bytes(int64_t M, int64_t N, int64_t K)
 int vited_linear_bwd_weight(const void* dY, int64_t lddy, const void* X, int64_t ldx, int dtype, int64_t M,
                             int64_t N, int64_t K, float* dW, float* dbias, int accumulate, float* workspace,
                             int64_t workspace_bytes, void* stream);
+
+/* ---- fused MLP branch of a block: y = x + fc2(gelu(fc1(LayerNorm(x)))) (vision_transformer.py:126,271; timm Mlp :115,:259) ---- */
+
+/* One kernel for the second half of Block.forward / CrossBlock.forward (SURVEY.md section 8(b) "optional fused mlp"): LayerNorm
+ * (eps as given), fc1 + bias, exact-erf GELU, fc2 + bias and the residual add, bf16 MFMA with fp32 accumulation; the LayerNorm
+ * output and the hidden activation stay on chip.  Covers dim 384 / hidden 1536 (every shipped pjs config); other shapes return
+ * VITED_ERR_UNSUPPORTED and the caller runs vited_layernorm_fwd + vited_gemm(GELU_GRAD) + vited_gemm(RESIDUAL) instead.
+ *   x, y        fp32 [rows, dim] (row strides ldx, ldy); y may not alias x
+ *   w1, w2      bf16 [hidden, dim], [dim, hidden] dense (the nn.Linear weights in the activation dtype); b1, b2, gamma, beta fp32
+ *   h, gd, u, mean, rstd   what the backward kernels read - LN(x) bf16 [rows, dim], gelu'(z) and gelu(z) bf16 [rows, hidden]
+ *               (dense), row statistics fp32 [rows] - all five given, or all five null for inference (nothing is saved) */
+int vited_mlp_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, const void* w1, const float* b1,
+                  const void* w2, const float* b2, float* y, int64_t ldy, void* h, void* gd, void* u, float* mean,
+                  float* rstd, int64_t rows, int64_t dim, int64_t hidden, float eps, void* stream);
 
 /* ---- optimizer step on the flat gradient buffer ----------------- */
 

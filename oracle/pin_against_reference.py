@@ -37,6 +37,8 @@ CASES = {
     'A_full': (vo.SHAPE_A, 2, True),
     'H_1x1_128': (vo.ViTEDShape(img_size=128, patch_size=16, num_classes=1, num_heads=6, depth=1, c_depth=1), 2, True),
     'H_full': (vo.SHAPE_H, 1, False),
+    # config H's token counts (1024 / 1025: the flash attention forward AND backward kernels) at 1 + 1 blocks, with backward
+    'H_1x1_512': (vo.ViTEDShape(img_size=512, patch_size=16, num_classes=1, num_heads=6, depth=1, c_depth=1), 2, True),
 }
 
 

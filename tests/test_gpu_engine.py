@@ -1,0 +1,204 @@
+"""The driven step on the GPU: fused clip + AdamW kernel against torch.optim.AdamW + clip_grad_norm_ (misc/optimizer.py:25-46,
+misc/utils.py:215-223), hipGraph replay against eager launches with a per-iteration learning rate and gradient accumulation
+(misc/engine.py:212-231), bf16 weight shadows after an update, and two data-parallel ranks driving the HIP model.
+
+Tolerances: the AdamW kernel evaluates the same expression as torch's fused kernel in a different association, so parameters
+and moments agree to fp32 rounding (rtol 2e-6 per step on values that are not catastrophically cancelled: atol tied to lr);
+graph replay vs eager launches of the SAME kernels must be bit-identical.
+"""
+import os
+import types
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from oracle import vited_oracle as vo
+
+pytestmark = pytest.mark.gpu
+bce = torch.nn.functional.binary_cross_entropy_with_logits
+
+
+def _hip_model(vited, s, gpu, dtype):
+    m = vited.VisionTransformerCustom(img_size=s.img_size, patch_size=s.patch_size, in_chans=s.in_chans, num_classes=s.num_classes,
+                                      embed_dim=s.embed_dim, depth=s.depth, c_depth=s.c_depth, num_heads=s.num_heads)
+    m.compute_dtype = dtype
+    return m.to(gpu)
+
+
+def test_flat_adamw_matches_torch_adamw_and_refreshes_shadows(vited, gpu):
+    torch.manual_seed(0)
+    shapes = [(384, 1152), (4, 384), (384, 3, 8, 8), (384,), (65, 130), (1536, 384), (1,), (1, 1, 384), (100, 36)]
+    mine = [torch.nn.Parameter(torch.randn(sh, device=gpu) * 0.1) for sh in shapes]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in mine]
+
+    def groups(ps):
+        return [{'params': [p for p in ps if p.ndim > 1]}, {'params': [p for p in ps if p.ndim <= 1], 'weight_decay': 0.0}]
+
+    kw = dict(lr=2e-3, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.05)
+    opt = vited.optim.FlatAdamW(groups(mine), **kw)
+    topt = torch.optim.AdamW(groups(ref), **kw)
+    flat = vited.engine.FlatGradients(mine, early=[mine[1], mine[3]])       # any layout of the flat buffer
+    rt = vited.functions.Runtime(img_size=64, patch_size=8, in_chans=3, num_classes=4, embed_dim=384, depth=1, c_depth=1, num_heads=12)
+    shadow_n = {i: rt.weight(mine[i]) for i in (0, 2, 5, 8)}
+    shadow_t = {i: rt.weight_t(mine[i])[0] for i in (0, 4, 5)}
+    opt.bind_flat(flat, types.SimpleNamespace(_runtimes={torch.bfloat16: rt}))
+    for it in range(4):
+        for p, q in zip(mine, ref):
+            g = torch.randn_like(p) * (3.0 if it == 1 else 0.01)       # step 1: the clip is active
+            p.grad.copy_(g)
+            q.grad = g.clone()
+        lr = 2e-3 / (1 + it)                                            # per-iteration schedule
+        for o in (opt, topt):
+            for grp in o.param_groups:
+                grp['lr'] = lr
+        want_norm = torch.nn.utils.clip_grad_norm_(ref, 1.0)
+        topt.step()
+        norm = opt.step_flat(1.0)
+        torch.testing.assert_close(norm, want_norm, rtol=1e-5, atol=1e-7)
+        assert float(flat.flat.abs().max()) == 0.0                      # zero_grad fused in
+        for i, (p, q) in enumerate(zip(mine, ref)):
+            torch.testing.assert_close(p, q, rtol=2e-6, atol=1e-3 * lr, msg=lambda m: f'step {it} param {i} {tuple(p.shape)}: {m}')
+            torch.testing.assert_close(opt.state[p]['exp_avg'], topt.state[q]['exp_avg'], rtol=1e-5, atol=1e-9)
+            torch.testing.assert_close(opt.state[p]['exp_avg_sq'], topt.state[q]['exp_avg_sq'], rtol=1e-5, atol=1e-12)
+        for i, sh in shadow_n.items():
+            assert torch.equal(sh, mine[i].detach().reshape(mine[i].shape[0], -1).to(torch.bfloat16)), f'shadow of param {i}'
+            assert rt.weight(mine[i]) is sh                             # the cache entry stays valid: no recast on the next forward
+        for i, sh in shadow_t.items():
+            assert torch.equal(sh, mine[i].detach().reshape(mine[i].shape[0], -1).t().contiguous().to(torch.bfloat16)), f'shadow_t of param {i}'
+    assert opt.num_updates == 4
+    sd = opt.state_dict()                                               # torch.optim.AdamW-shaped state (misc/utils.py:130-142)
+    assert set(sd['state'][0].keys()) >= {'step', 'exp_avg', 'exp_avg_sq'} and float(sd['state'][0]['step']) == 4.0
+
+
+class _Sched:
+    """Stand-in for the reference's per-iteration scheduler (misc/lr_scheduler.py via misc/engine.py:228)."""
+
+    def __init__(self, opt, base):
+        self.opt, self.base = opt, base
+
+    def step_update(self, n):
+        for g in self.opt.param_groups:
+            g['lr'] = self.base / (1.0 + 0.5 * n)
+
+
+@pytest.mark.parametrize('optimizer', ['flat_hip', 'torch_capturable'])
+@pytest.mark.parametrize('amp,accum', [(False, 1), (True, 1), (False, 2)])
+def test_graph_replay_equals_eager_with_lr_schedule_and_accumulation(vited, gpu, optimizer, amp, accum):
+    """TrainStep(use_graph=True) replays three hipGraphs per step.  With a learning rate that changes after every update
+    and (accum = 2) two micro-batches per update it must produce, bit for bit, the parameters of the eagerly launched
+    TrainStep - so the replayed update really reads the scheduler's value and the accumulation really accumulates.  bf16
+    (amp) adds the weight shadows: they are refreshed inside the update, so an eval forward right after training equals
+    the forward of a freshly loaded checkpoint."""
+    s = vo.ViTEDShape(depth=1, c_depth=1)
+    torch.manual_seed(3)
+    init = _hip_model(vited, s, gpu, None).state_dict()
+    models, steps = [], []
+    for use_graph in (False, True):
+        m = _hip_model(vited, s, gpu, None)
+        m.load_state_dict(init)
+        groups = vited.engine.param_groups_no_decay_1d(m)
+        kw = dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05)
+        opt = vited.optim.FlatAdamW(groups, **kw) if optimizer == 'flat_hip' else torch.optim.AdamW(groups, fused=True, capturable=True, **kw)
+        steps.append(vited.engine.TrainStep(m, opt, clip_grad=5.0, amp=amp, use_graph=use_graph, accumulation_steps=accum,
+                                            lr_scheduler=_Sched(opt, 1e-3)))
+        models.append(m)
+    g = torch.Generator().manual_seed(9)
+    for it in range(7 * accum):
+        x = torch.randn(8, 2, 3, 64, 64, generator=g).clamp(-1, 1).to(gpu)
+        y = (torch.rand(8, 4, generator=g) > 0.6).float().to(gpu)
+        le, lg = [float(st.step(x, y)) for st in steps]
+        assert le == lg, (it, le, lg)
+    assert steps[1]._g1 is not None and steps[1]._g2 is not None and steps[0].num_updates == steps[1].num_updates == 7
+    assert float(steps[0].last_norm) == float(steps[1].last_norm)
+    for (n, pe), (_, pg) in zip(models[0].named_parameters(), models[1].named_parameters()):
+        assert torch.equal(pe, pg), f'{n}: graph replay differs from eager launches'
+    # the schedule took effect: a frozen lr = 1e-3 run lands elsewhere
+    assert not torch.equal(models[0].head.weight, init['head.weight'])
+    x = torch.randn(4, 2, 3, 64, 64, generator=g).clamp(-1, 1).to(gpu)
+    with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16, enabled=amp):
+        after = [m.eval()(x) for m in models]
+        fresh = _hip_model(vited, s, gpu, None)
+        fresh.load_state_dict(models[1].state_dict())
+        want = fresh.eval()(x)
+    assert torch.equal(after[0], want) and torch.equal(after[1], want), 'stale bf16 weight shadows after the last update'
+
+
+def test_graph_survives_workspace_growth_after_capture(vited, gpu):
+    """A larger eager op after capture grows the shared workspace; the captured kernels keep their (retired, still alive)
+    buffer, so replays stay correct."""
+    s = vo.ViTEDShape(depth=1, c_depth=1)
+    torch.manual_seed(5)
+    models = [_hip_model(vited, s, gpu, torch.float32) for _ in range(2)]
+    models[1].load_state_dict(models[0].state_dict())
+    steps = [vited.engine.TrainStep(m, vited.optim.FlatAdamW(vited.engine.param_groups_no_decay_1d(m), lr=1e-3), amp=False, use_graph=ug)
+             for m, ug in zip(models, (False, True))]
+    g = torch.Generator().manual_seed(1)
+    for it in range(6):
+        x = torch.randn(4, 2, 3, 64, 64, generator=g).clamp(-1, 1).to(gpu)
+        y = (torch.rand(4, 4, generator=g) > 0.6).float().to(gpu)
+        if it == 4:
+            before = vited.ops.workspace(4, gpu).numel()
+            big = torch.randn(4096, 3000, device=gpu)
+            vited.ops.sum_rows(big)                                    # batch 4096 x width 3000: grows the workspace
+            grown = vited.ops.workspace(4, gpu).numel()
+            if grown > before:
+                scribble = torch.full((grown,), float('nan'), device=gpu)   # whoever owns recycled memory writes to it
+                del scribble
+        assert float(steps[0].step(x, y)) == float(steps[1].step(x, y))
+    for (n, pe), (_, pg) in zip(models[0].named_parameters(), models[1].named_parameters()):
+        assert torch.equal(pe, pg), n
+
+
+# ---------------------------------------------------------------------------------------------
+# two data-parallel ranks drive the HIP model (gloo moves the CUDA tensors; RCCL needs one GPU per rank)
+# ---------------------------------------------------------------------------------------------
+def _rank(rank, world, port, out):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+    import vited_amd as V
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0')
+    dist.init_process_group('gloo', init_method='env://', world_size=world, rank=rank)
+    dev = torch.device('cuda:0')
+    s = vo.ViTEDShape(depth=1, c_depth=1)
+    torch.manual_seed(100 + rank)
+    m = V.VisionTransformerCustom(img_size=s.img_size, patch_size=s.patch_size, num_classes=s.num_classes, embed_dim=s.embed_dim,
+                                  depth=1, c_depth=1, num_heads=s.num_heads).to(dev)
+    m.compute_dtype = torch.float32
+    V.engine.broadcast_parameters(m)
+    opt = V.optim.FlatAdamW(V.engine.param_groups_no_decay_1d(m), lr=1e-3, weight_decay=0.05)
+    step = V.engine.TrainStep(m, opt, clip_grad=5.0, amp=False, use_graph=True)
+    assert len(step.flat.buckets()) == 2
+    g = torch.Generator().manual_seed(7)
+    for it in range(4):                         # 2 eager + capture + replays: the exchange sits between the graphs
+        x = torch.randn(8, 2, 3, 64, 64, generator=g).clamp(-1, 1)
+        y = (torch.rand(8, 4, generator=g) > 0.6).float()
+        step.step(x[rank::world].to(dev), y[rank::world].to(dev))
+    params = torch.cat([p.detach().reshape(-1) for p in m.parameters()]).cpu()
+    gathered = [torch.empty_like(params) for _ in range(world)]
+    dist.all_gather(gathered, params)
+    if rank == 0:
+        torch.save({'same': all(torch.equal(t, gathered[0]) for t in gathered), 'state': {k: v.cpu() for k, v in m.state_dict().items()}}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_match_single_process(vited, gpu, tmp_path):
+    out = str(tmp_path / 'r0.pt')
+    mp.spawn(_rank, args=(2, 29700 + os.getpid() % 200, out), nprocs=2, join=True)
+    res = torch.load(out, weights_only=True)
+    assert res['same']
+    s = vo.ViTEDShape(depth=1, c_depth=1)
+    torch.manual_seed(100)
+    m = _hip_model(vited, s, gpu, torch.float32)
+    opt = vited.optim.FlatAdamW(vited.engine.param_groups_no_decay_1d(m), lr=1e-3, weight_decay=0.05)
+    step = vited.engine.TrainStep(m, opt, clip_grad=5.0, amp=False)
+    g = torch.Generator().manual_seed(7)
+    for it in range(4):
+        x = torch.randn(8, 2, 3, 64, 64, generator=g).clamp(-1, 1)
+        y = (torch.rand(8, 4, generator=g) > 0.6).float()
+        step.step(x.to(gpu), y.to(gpu))
+    for k, v in m.state_dict().items():
+        # mean of the two shard gradients == full-batch gradient up to fp32 summation order; AdamW amplifies that on ~0 gradients
+        torch.testing.assert_close(res['state'][k], v.cpu(), rtol=1e-3, atol=2e-4, msg=lambda msg: f'{k}: {msg}')

@@ -46,7 +46,7 @@ def _targets(batch, s, dev):
     return (vo.closed_form((batch, s.num_classes), 77, 1.0) > 0.2).float().to(dev)
 
 
-@pytest.mark.parametrize('name', ['T', 'A_1x1', 'A_2x2', 'H_1x1_128', 'A_full', 'H_full'])
+@pytest.mark.parametrize('name', ['T', 'A_1x1', 'A_2x2', 'H_1x1_128', 'H_1x1_512', 'A_full', 'H_full'])
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_against_reference_fixtures(vited, gpu, name, dtype):
     fx = _fixture(name)
@@ -103,10 +103,12 @@ def _check_bf16_grads_like_torch_autocast(s, batch, g_hip):
     """bf16 gradients on the closed-form fixtures are ill-conditioned for EVERY bf16 implementation
     (PyTorch's own CPU bf16 autocast of the oracle is off by > 100 % on some tensors), so the
     yardstick for the MFMA path is that autocast run: the HIP path must be about as close to the
-    fp32 gradients as PyTorch bf16 autocast is - globally within 1.5x (+1e-2), per tensor within
-    3x (+5e-2).  The 8+8-block closed-form case is chaotic in bf16 (two bf16 implementations differ
-    from each other as much as from fp32), so there only a 4x global bound is asserted; the
-    well-conditioned full-depth check is test_against_oracle_random_init[8-*]."""
+    fp32 gradients as PyTorch bf16 autocast is - globally within 1.5x (+1e-2) at every depth, per tensor
+    within 3x (+5e-2) on the shallow cases (on the 8+8-block closed-form case individual small tensors are
+    chaotic in bf16 - two bf16 implementations differ from each other as much as from fp32 - so per tensor it
+    is the per-block comparison of test_bf16_error_growth_per_block that applies there).  Round 1 carried a 4x
+    allowance for the deep case; measured at round 2 (tests/diag_bf16_gradients.py) the HIP path is at
+    0.74x of autocast's error there (8.98e-2 vs 1.22e-1), so the allowance is gone."""
     g32 = _oracle_grads(s, batch, autocast=False)
     gac = _oracle_grads(s, batch, autocast=True)
 
@@ -117,7 +119,7 @@ def _check_bf16_grads_like_torch_autocast(s, batch, g_hip):
 
     t_hip, t_ac = total(g_hip), total(gac)
     deep = s.depth + s.c_depth >= 8
-    assert t_hip <= (4.0 if deep else 1.5) * t_ac + 1e-2, f'global bf16 gradient error {t_hip:.3e} vs torch autocast {t_ac:.3e}'
+    assert t_hip <= 1.5 * t_ac + 1e-2, f'global bf16 gradient error {t_hip:.3e} vs torch autocast {t_ac:.3e}'
     if deep:
         return
     gmax = max(float(g.norm()) for g in g32.values())
@@ -174,6 +176,30 @@ def test_against_oracle_random_init(vited, gpu, dtype, depth):
         assert total(gh) < 2e-2 and total(gh) <= 1.5 * total(gac) + 1e-3, (total(gh), total(gac))
 
 
+@pytest.mark.parametrize('case', ['rand8', 'A_full'])
+def test_bf16_error_growth_per_block(vited, gpu, case):
+    """Where bf16 error enters, block by block (taps in functions.py): the output of every encoder / decoder block in
+    forward and the gradient w.r.t. every block's input in backward, HIP bf16 vs the fp32 oracle, next to PyTorch's own CPU
+    bf16 autocast of the oracle on the same inputs.  The MFMA path may not lose accuracy faster than autocast at any block
+    (1.3x + 2e-3), on reference-style random init (well conditioned) and on the 8+8-block closed-form fixture (the case whose
+    gradient error was 2.9x autocast's in round 1)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('diag_bf16_gradients', os.path.join(os.path.dirname(os.path.abspath(__file__)), 'diag_bf16_gradients.py'))
+    diag = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(diag)
+    r = diag.anatomy(case, gpu)
+    for name, fwd_hip, fwd_ac, dx_hip, dx_ac in r['rows']:
+        assert fwd_hip <= 1.3 * fwd_ac + 2e-3, f'{case} {name}: forward error {fwd_hip:.3e} vs autocast {fwd_ac:.3e}'
+        assert dx_hip <= 1.3 * dx_ac + 2e-3, f'{case} {name}: d(input) error {dx_hip:.3e} vs autocast {dx_ac:.3e}'
+    assert r['grads'][0] <= 1.25 * r['grads'][1] + 1e-3, r['grads']
+    assert r['logits'][0] <= 1.3 * r['logits'][1] + 1e-3, r['logits']
+    if case == 'A_full':
+        # the tensors the textbook delta = rowsum(dO o O) hurt (near-uniform attention): now within reach of autocast
+        for n in ('cross_blocks.7.cross_attn.q.weight', 'cross_blocks.0.cross_attn.q.weight'):
+            e_hip, e_ac, _ = r['per_param'][n]
+            assert e_hip <= 3 * e_ac + 5e-2, f'{n}: HIP {e_hip:.3e} vs autocast {e_ac:.3e}'
+
+
 def test_train_equals_eval_and_no_grad_saves_nothing(vited, gpu):
     s = vo.ViTEDShape(depth=1, c_depth=1)
     model = vo.fill_closed_form_(_hip_model(vited, s, gpu, torch.bfloat16))
@@ -225,21 +251,88 @@ def test_hisfrag_two_stage_training_step(vited, gpu):
         assert err < 1e-3, f'{n}: {err:.3e}'
 
 
-def test_pairwise_similarity_matches_one_shot_pairs(vited, gpu):
-    """BASELINE config 5 on one rank: encoder once per image + decoder on gathered pairs (image-2 gather
-    inside the patch-embed kernel) == the naive one-shot forward on stacked pairs."""
-    s = vo.ViTEDShape(img_size=64, patch_size=8, num_classes=1, depth=1, c_depth=1)
-    model = vo.fill_closed_form_(_hip_model(vited, s, gpu, torch.bfloat16)).eval()
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_pairwise_similarity_matches_the_oracle(vited, gpu, dtype):
+    """BASELINE config 5 on one rank against the CPU ORACLE: encoder once per image + decoder on gathered pairs (image-2
+    gather by index inside the patch-embed kernel, features by index, pair batch 64) == the oracle's naive one-shot forward
+    on stacked pairs (tests/hisfrag_evaluation_test.py:18-99 ``eval_standard``).  H-shaped block: 6 heads x 64, 256 / 257
+    tokens (the flash attention kernels), 1 + 1 blocks.  fp32 kernels: 1e-3; bf16: 3e-2 (scores are stored as fp16)."""
+    s = vo.ViTEDShape(img_size=256, patch_size=16, num_classes=1, num_heads=6, depth=1, c_depth=1)
+    torch.manual_seed(11)
+    oracle = vo.OracleViTED(s).eval()
+    model = _hip_model(vited, s, gpu, dtype).eval()
+    model.load_state_dict(oracle.state_dict())
     g = torch.Generator().manual_seed(5)
-    imgs = torch.randn(13, 3, 64, 64, generator=g).clamp(-1, 1).to(gpu)
-    sim = vited.engine.pairwise_similarity(model, imgs, block=5, pair_batch=16)
-    i, j = torch.triu_indices(13, 13, device=gpu)
+    n = 13
+    imgs = torch.randn(n, 3, 256, 256, generator=g).clamp(-1, 1)
+    sim = vited.engine.pairwise_similarity(model, imgs.to(gpu), block=5, pair_batch=64, amp=dtype == torch.bfloat16)
+    i, j = torch.triu_indices(n, n)
     with torch.no_grad():
-        ref = model(torch.stack([imgs[i], imgs[j]], dim=1)).reshape(-1)
-    torch.testing.assert_close(sim[i, j].float(), ref, rtol=2e-2, atol=2e-2)
+        ref = oracle(torch.stack([imgs[i], imgs[j]], dim=1)).reshape(-1)
+    tol = dict(rtol=2e-3, atol=2e-3) if dtype == torch.float32 else dict(rtol=3e-2, atol=3e-2)   # fp16 storage: 1e-3 relative
+    torch.testing.assert_close(sim[i, j].float().cpu(), ref, **tol)
     assert torch.equal(sim, sim.t()) and sim.dtype == torch.float16
     with pytest.raises(NotImplementedError):
-        model(model(imgs[:2], forward_first_part=True), imgs, x2_index=torch.tensor([0, 1], device=gpu))
+        model(model(imgs[:2].to(gpu), forward_first_part=True), imgs.to(gpu), x2_index=torch.tensor([0, 1], device=gpu))
+
+
+def test_batch_1024_rows_match_batch_8(vited, gpu):
+    """The bench geometry on the default kernel path: config A, bf16, B = 1024 (token matrices of 65,536 / 66,560 rows:
+    512-1,560 output tiles, the XCD remap, the 512-way split weight-gradient GEMMs).  Rows 0..7 of the 1024-batch must give
+    the logits - and, with a loss that only sees those rows, the parameter gradients - of the same 8 pairs run alone.
+    Both runs round to bf16 at the same places, so they differ only by fp32 summation order inside tiles and splits."""
+    s = vo.SHAPE_A
+    torch.manual_seed(4)
+    model = _hip_model(vited, s, gpu, torch.bfloat16)
+    x = torch.randn(1024, 2, 3, 64, 64, device=gpu).clamp_(-1, 1)
+    y = (torch.rand(1024, 4, device=gpu) > 0.75).float()
+
+    def run(xb, yb):
+        model.zero_grad(set_to_none=True)
+        out = model(xb)
+        torch.nn.functional.binary_cross_entropy_with_logits(out[:8], yb[:8]).backward()
+        return out.detach()[:8].clone(), {n: p.grad.clone() for n, p in model.named_parameters()}
+
+    l_small, g_small = run(x[:8], y[:8])
+    l_big, g_big = run(x, y)
+    torch.testing.assert_close(l_big, l_small, rtol=2e-2, atol=2e-2)
+    num = sum(float((g_big[n].double() - g_small[n].double()).norm() ** 2) for n in g_small)
+    den = sum(float(g_small[n].double().norm() ** 2) for n in g_small)
+    assert (num / den) ** 0.5 < 2e-2, f'global gradient difference {(num / den) ** 0.5:.3e}'
+    gmax = max(float(v.norm()) for v in g_small.values())
+    for n in g_small:
+        den = float(g_small[n].norm())
+        if den < 1e-3 * gmax:
+            continue
+        err = float((g_big[n] - g_small[n]).norm()) / den
+        assert err < 5e-2, f'{n}: B=1024 vs B=8 gradient differs by {err:.3e}'
+
+
+def test_mine_pairs_on_device(vited, gpu):
+    """engine.mine_pairs / hisfrag_prepare_data on GPU tensors (hisfrag.py:117-155): same pairs as the literal loop."""
+    eng = vited.engine
+    g = torch.Generator().manual_seed(5)
+    for n, classes in ((24, 8), (7, 2), (5, 5)):
+        targets = torch.randint(0, classes, (n,), generator=g)
+        pos_ref = [(i, j) for i in range(n) for j in range(i + 1, n) if targets[i] == targets[j]]
+        neg_ref = {(i, j) for i in range(n) for j in range(i + 1, n) if targets[i] != targets[j]}
+        groups, labels = eng.mine_pairs(targets.to(gpu))
+        assert groups.device.type == 'cuda' and labels.device.type == 'cuda'
+        npos, nneg = len(pos_ref), min(len(neg_ref), 2 * len(pos_ref))
+        assert groups.shape == (npos + nneg, 2)
+        assert [tuple(r) for r in groups[:npos].tolist()] == pos_ref
+        got = [tuple(r) for r in groups[npos:].tolist()]
+        assert len(set(got)) == nneg and set(got) <= neg_ref
+        assert labels[:npos].eq(1).all() and labels[npos:].eq(0).all()
+    s = vo.ViTEDShape(img_size=64, patch_size=8, num_classes=1, depth=1, c_depth=1)
+    model = vo.fill_closed_form_(_hip_model(vited, s, gpu, torch.float32))
+    imgs = torch.randn(6, 3, 64, 64, generator=g).clamp(-1, 1).to(gpu)
+    targets = torch.tensor([0, 0, 1, 1, 2, 0], device=gpu)
+    (x2, feats), labels = eng.hisfrag_prepare_data(model, imgs, targets, amp=False)
+    out = model(feats, x2)
+    assert out.shape == labels.shape and feats.requires_grad
+    torch.nn.functional.binary_cross_entropy_with_logits(out, labels).backward()
+    assert model.blocks[0].attn.qkv.weight.grad is not None      # one backward through both forwards (hisfrag.py:150-159)
 
 
 @pytest.mark.parametrize('shape', ['A2', 'one_class', 'T'])
@@ -297,7 +390,7 @@ def test_train_step_graph_replay_matches_eager_steps_and_the_oracle(vited, gpu, 
         opt_o.step()
         assert losses[0] == losses[1], (it, losses)
         assert abs(losses[0] - float(lo.detach())) < 1e-3 * max(1.0, abs(float(lo.detach()))), (it, losses, float(lo.detach()))
-    assert steps[1]._g_fb is not None          # the graph path really replayed (2 eager warm-ups, then capture)
+    assert steps[1]._g1 is not None          # the graph path really replayed (2 eager warm-ups, then capture)
     po = dict(oracle.named_parameters())
     for (n, pe), (_, pg) in zip(models[0].named_parameters(), models[1].named_parameters()):
         assert torch.equal(pe, pg), f'{n}: graph replay differs from eager launches'

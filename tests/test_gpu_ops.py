@@ -353,3 +353,55 @@ def test_attention_fwd_bwd(vited, gpu, dtype, B, H, Nq, Nk, hd):
 def test_ops_refuse_cpu_tensors(vited, gpu):
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         vited.ops.cast(torch.zeros(4), torch.bfloat16)
+
+
+# ---------------------------------------------------------------------------------------------
+# fused MLP branch (vited_mlp_fwd): y = x + fc2(gelu(fc1(LN(x))))  (vision_transformer.py:126,271; timm Mlp)
+# ---------------------------------------------------------------------------------------------
+def _mlp_case(gpu, rows, seed, ld_pad=0):
+    d, hid = 384, 1536
+    xs = _rand((rows, d + ld_pad), gpu, seed)[:, :d]                    # optionally row-strided
+    gamma, beta = 1.0 + 0.2 * _rand((d,), gpu, seed + 1), 0.1 * _rand((d,), gpu, seed + 2)
+    w1, b1 = _rand((hid, d), gpu, seed + 3, 0.06), 0.1 * _rand((hid,), gpu, seed + 4)
+    w2, b2 = _rand((d, hid), gpu, seed + 5, 0.03), 0.1 * _rand((d,), gpu, seed + 6)
+    return xs, gamma, beta, w1, b1, w2, b2
+
+
+@pytest.mark.parametrize('rows', [128, 65 * 3, 1, 16, 4160, 640 + 17])
+def test_mlp_fused_forward_and_saved_tensors(vited, gpu, rows):
+    """The fused kernel against plain PyTorch fp32 of the same op chain evaluated on the SAME bf16-rounded operands
+    (LayerNorm output, weights, hidden activation rounded where the kernel rounds them), ragged row counts included:
+    y within 2e-3 (fp32 accumulation order only), saved bf16 tensors within one bf16 ulp of the reference values."""
+    ops = vited.ops
+    x, gamma, beta, w1, b1, w2, b2 = _mlp_case(gpu, rows, 100 + rows, ld_pad=8 if rows == 128 else 0)
+    w1b, w2b = w1.to(torch.bfloat16), w2.to(torch.bfloat16)
+    y, (mean, rstd, h, gd, u) = ops.mlp_fwd(x, gamma, beta, w1b, b1, w2b, b2, 1e-6, save=True)
+    y2, none = ops.mlp_fwd(x, gamma, beta, w1b, b1, w2b, b2, 1e-6, save=False)
+    assert none is None and torch.equal(y, y2)
+    xr = x.contiguous()
+    mu, var = xr.mean(-1), xr.var(-1, unbiased=False)
+    h_ref = F.layer_norm(xr, (384,), gamma, beta, 1e-6)
+    torch.testing.assert_close(mean, mu, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(rstd, (var + 1e-6).rsqrt(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(h.float(), h_ref, **BF16_OUT)
+    z = h.float() @ w1b.float().t() + b1                               # from the kernel's own (bf16) h: isolates fc1
+    u_ref = F.gelu(z)
+    cdf = 0.5 * (1 + torch.erf(z / math.sqrt(2)))
+    gd_ref = cdf + z * torch.exp(-0.5 * z * z) / math.sqrt(2 * math.pi)
+    torch.testing.assert_close(u.float(), u_ref, **BF16_OUT)
+    torch.testing.assert_close(gd.float(), gd_ref, **BF16_OUT)
+    y_ref = xr + u.float() @ w2b.float().t() + b2                      # from the kernel's own (bf16) u: isolates fc2 + residual
+    torch.testing.assert_close(y, y_ref, rtol=2e-3, atol=2e-3)
+    # and end to end against the unfused kernels of the same library
+    hh, m2, r2 = ops.layernorm_fwd(xr, gamma, beta, 1e-6, torch.bfloat16)
+    gd2, u2 = ops.gemm(hh, w1b, epilogue=vited._lib.EPI_GELU_GRAD, bias=b1)
+    y3 = ops.gemm(u2, w2b, epilogue=vited._lib.EPI_RESIDUAL, bias=b2, residual=xr)
+    torch.testing.assert_close(y, y3, rtol=5e-3, atol=5e-3)   # u differs by one bf16 ulp in places (fp32 summation order before the rounding)
+
+
+def test_mlp_fused_rejects_other_shapes(vited, gpu):
+    ops = vited.ops
+    x = _rand((64, 256), gpu, 1)
+    with pytest.raises(RuntimeError, match='unsupported'):
+        ops.mlp_fwd(x, torch.ones(256, device=gpu), torch.zeros(256, device=gpu), _rand((1024, 256), gpu, 2).bfloat16(), torch.zeros(1024, device=gpu),
+                    _rand((256, 1024), gpu, 3).bfloat16(), torch.zeros(256, device=gpu), 1e-6)

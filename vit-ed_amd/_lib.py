@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get('VITED_LIB') or os.path.join(_HERE, 'libvited_hip.so')
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'vited.h')
 
 F32, BF16 = 0, 1
-EPI_STORE, EPI_GELU, EPI_RESIDUAL, EPI_MUL_GELU_GRAD, EPI_STORE_F32 = 0, 1, 2, 3, 4
+EPI_STORE, EPI_GELU, EPI_RESIDUAL, EPI_MUL_GELU_GRAD, EPI_STORE_F32, EPI_MUL, EPI_GELU_GRAD = 0, 1, 2, 3, 4, 5, 6
 B_NK, B_KN = 0, 1
 
 _p, _i64, _i, _f = C.c_void_p, C.c_int64, C.c_int, C.c_float
@@ -42,6 +42,7 @@ SIGNATURES = {
                         _i64, _i, _p]),
     'vited_linear_bwd_weight_workspace_bytes': (_i64, [_i64, _i64, _i64]),
     'vited_linear_bwd_weight': (_i, [_p, _i64, _p, _i64, _i, _i64, _i64, _i64, _p, _p, _i, _p, _i64, _p]),
+    'vited_mlp_fwd': (_i, [_p, _i64, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _p, _p, _p, _p, _i64, _i64, _i64, _f, _p]),
     'vited_adamw_workspace_bytes': (_i64, []),
     'vited_adamw_step': (_i, [_p, _i, _i64, _p, _i64, _p, _f, _i, _p, _p, _i64, _p]),
     'vited_attention_fwd': (_i, [_p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _p, _i, _i64, _i,

@@ -169,7 +169,6 @@ attn_bwd_small_kernel(AttnArgs a) {
     const bf16* qb = (const bf16*)a.q + b * a.q_bs + hoff;
     const bf16* kb = (const bf16*)a.k + b * a.k_bs + hoff;
     const bf16* vb = (const bf16*)a.v + b * a.v_bs + hoff;
-    const bf16* ob = (const bf16*)a.o + b * a.o_bs + hoff;
     const bf16* dob = (const bf16*)a.d_o + b * a.o_bs + hoff;
     // wave-private LDS: image slot 0 holds K during phase T and Q during phase N, slot 1 holds dO.  Two slots
     // instead of three is what lets a third workgroup fit on a CU; everything is written and read by the same
@@ -189,7 +188,7 @@ attn_bwd_small_kernel(AttnArgs a) {
 
     // every global load of the (batch, head) item is issued before the first use: one exposed memory latency per
     // wave instead of one per query tile (the staging / delta code below used to sit between the loads)
-    bf16x8 kf[NKT][C::KCH], vf[NKT][C::KCH], qf[NQT][C::KCH], dof[NQT][C::KCH], of[NQT][C::KCH];
+    bf16x8 kf[NKT][C::KCH], vf[NKT][C::KCH], qf[NQT][C::KCH], dof[NQT][C::KCH];
     float lse_r[NQT];
 #pragma unroll
     for (int t = 0; t < NKT; ++t) {
@@ -200,7 +199,6 @@ attn_bwd_small_kernel(AttnArgs a) {
     for (int i = 0; i < NQT; ++i) {
         load_row_frags<HD>(qb, a.q_ts, 16 * i, nq, fr, g, qf[i]);
         load_row_frags<HD>(dob, a.o_ts, 16 * i, nq, fr, g, dof[i]);
-        load_row_frags<HD>(ob, a.o_ts, 16 * i, nq, fr, g, of[i]);
         const int q = 16 * i + fr;
         lse_r[i] = a.lse[(b * a.heads + h) * a.nq + (q < nq ? q : nq - 1)];
     }
@@ -209,18 +207,8 @@ attn_bwd_small_kernel(AttnArgs a) {
     for (int t = 0; t < NKT; ++t) stage_tile<HD>(k_s, 16 * t, nk, fr, g, kf[t]);
 #pragma unroll
     for (int i = 0; i < NQT; ++i) {
-        // delta[q] = sum_d O[q][d] dO[q][d]; lse in log2 units
-        float dl = 0.f;
-#pragma unroll
-        for (int c = 0; c < C::KCH; ++c)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) dl = fmaf((float)of[i][c][e], (float)dof[i][c][e], dl);
-        dl = group_sum4(dl);
         const int q = 16 * i + fr;
-        if (g == 0) {
-            del_s[q] = dl;
-            lse_s[q] = lse_r[i] * LOG2E;
-        }
+        if (g == 0) lse_s[q] = lse_r[i] * LOG2E;   // lse in log2 units
     }
     {
         const bf16x8 z[C::KCH] = {};
@@ -232,8 +220,14 @@ attn_bwd_small_kernel(AttnArgs a) {
 #pragma unroll
     for (int i = 0; i < NQT; ++i) {
         const int q = 16 * i + fr;
-        const float lse2 = lse_s[q], dl = del_s[q];
-        f32x4 ds[NKT + 1];
+        const float lse2 = lse_s[q];
+        f32x4 ds[NKT + 1], dpv[NKT];
+        // delta[q] = sum_j P[q][j] dP[q][j], taken from the SAME fp32 P and dP the softmax backward uses (the whole key row
+        // of a query is in this wave: 4 lane groups x NKT tiles x 4).  The textbook rowsum(dO o O) equals it only in exact
+        // arithmetic: with O rounded to bf16 the mismatch is a per-row bias eps_q that dQ = sum_j P (dP - delta) K picks up
+        // along the mean key direction - on near-uniform attention (cancellation-dominated dS) that bias was 16x the error
+        // of PyTorch's bf16 autocast on d(cross_attn.q) (tests/diag_bf16_gradients.py).  It also saves reading O.
+        float dl = 0.f;
 #pragma unroll
         for (int t = 0; t < NKT; ++t) {
             f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
@@ -246,9 +240,17 @@ attn_bwd_small_kernel(AttnArgs a) {
             for (int e = 0; e < 4; ++e) {
                 float pe = __builtin_amdgcn_exp2f(fmaf(s[e], sc, -lse2));
                 if (t == NKT - 1) pe = (16 * t + 4 * g + e) < nk ? pe : 0.f;   // only the last key tile can be ragged
-                ds[t][e] = pe * (dp[e] - dl);
+                ds[t][e] = pe;
+                dl = fmaf(pe, dp[e], dl);
             }
+            dpv[t] = dp;
         }
+        dl = group_sum4(dl);
+        if (g == 0) del_s[q] = dl;          // phase N reads it back (same wave: DS operations execute in order)
+#pragma unroll
+        for (int t = 0; t < NKT; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ds[t][e] *= dpv[t][e] - dl;
         ds[NKT] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int dt = 0; dt < C::DT; ++dt) {

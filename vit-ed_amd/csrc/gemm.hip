@@ -15,9 +15,9 @@ extern "C" int vited_gemm(const void* A, int64_t lda, const void* B, int64_t ldb
     if (!A || !B || !out || M <= 0 || N <= 0 || K <= 0 || lda < K || ldo < N) return VITED_ERR_BAD_ARG;
     if (b_layout != VITED_B_NK && b_layout != VITED_B_KN) return VITED_ERR_BAD_ARG;
     if (ldb < (b_layout == VITED_B_NK ? K : N)) return VITED_ERR_BAD_ARG;
-    if (epilogue == VITED_EPI_GELU && !out2) return VITED_ERR_BAD_ARG;
+    if ((epilogue == VITED_EPI_GELU || epilogue == VITED_EPI_GELU_GRAD) && !out2) return VITED_ERR_BAD_ARG;
     if (epilogue == VITED_EPI_RESIDUAL && !residual) return VITED_ERR_BAD_ARG;
-    if (epilogue == VITED_EPI_MUL_GELU_GRAD && !aux) return VITED_ERR_BAD_ARG;
+    if ((epilogue == VITED_EPI_MUL_GELU_GRAD || epilogue == VITED_EPI_MUL) && !aux) return VITED_ERR_BAD_ARG;
     if (rows_per_batch < 0 || (rows_per_batch > 0 && (out_rows_per_batch < rows_per_batch + row_offset || row_offset < 0)))
         return VITED_ERR_BAD_ARG;
     EpiParams ep;

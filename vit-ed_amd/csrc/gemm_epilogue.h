@@ -4,10 +4,10 @@
 
 struct EpiParams {
     const float* bias;      // [N] or null
-    const void* aux;        // T [M, N] (ldo)   - MUL_GELU_GRAD
+    const void* aux;        // T [M, N] (ldo)   - MUL_GELU_GRAD, MUL
     const float* residual;  // fp32              - RESIDUAL
     void* out;              // T [M, N] (ldo), fp32 for RESIDUAL
-    void* out2;             // T [M, N] (ldo)   - GELU
+    void* out2;             // T [M, N] (ldo)   - GELU, GELU_GRAD
     int64_t ldo;
     int64_t rows_per_batch, out_rows_per_batch, row_offset;
     int residual_bcast;
@@ -24,6 +24,11 @@ __device__ __forceinline__ void epilogue_store(const EpiParams& p, int64_t m, in
     } else if constexpr (EPI == VITED_EPI_GELU) {
         ((T*)p.out)[m * p.ldo + n] = from_f32<T>(acc);
         ((T*)p.out2)[m * p.ldo + n] = from_f32<T>(gelu_f(acc));
+    } else if constexpr (EPI == VITED_EPI_GELU_GRAD) {
+        ((T*)p.out)[m * p.ldo + n] = from_f32<T>(gelu_grad_f(acc));
+        ((T*)p.out2)[m * p.ldo + n] = from_f32<T>(gelu_f(acc));
+    } else if constexpr (EPI == VITED_EPI_MUL) {
+        ((T*)p.out)[m * p.ldo + n] = from_f32<T>(acc * to_f32(((const T*)p.aux)[m * p.ldo + n]));
     } else if constexpr (EPI == VITED_EPI_RESIDUAL) {
         int64_t orow = m, rrow = m;
         if (p.rows_per_batch > 0) {

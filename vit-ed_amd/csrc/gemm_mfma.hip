@@ -43,6 +43,15 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                      (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
+// The same LDS-DMA issued from inline asm: invisible to hipcc's waitcnt bookkeeping, which otherwise drains a ring that is more
+// than one stage deep (it puts s_waitcnt vmcnt(0) in front of the first ds_read whenever it cannot prove the stages apart - the
+// TN_STAGES == 3 build of round 1 measured exactly that drain, not the ring).  The caller counts vmcnt itself.
+__device__ __forceinline__ void glds16_asm(const void* g, void* l) {
+    unsigned keep;
+    const unsigned dst = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)l;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(__builtin_amdgcn_readfirstlane(dst)) : "memory");
+}
 
 // bijective XCD-aware remap: blocks that share an XCD (bid % 8) get a contiguous run of tiles
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -166,8 +175,8 @@ bool gemm_nt_mfma_supported(const void* A, int64_t lda, const void* B, int64_t l
     if (K % 64 || N % 16 || lda % 8 || ldb % 8 || ep.ldo % 8) return false;
     if (!al16(A) || !al16(B) || !al16(ep.out)) return false;
     if (ep.bias && !al16(ep.bias)) return false;
-    if (epilogue == VITED_EPI_GELU && !al16(ep.out2)) return false;
-    if (epilogue == VITED_EPI_MUL_GELU_GRAD && !al16(ep.aux)) return false;
+    if ((epilogue == VITED_EPI_GELU || epilogue == VITED_EPI_GELU_GRAD) && !al16(ep.out2)) return false;
+    if ((epilogue == VITED_EPI_MUL_GELU_GRAD || epilogue == VITED_EPI_MUL) && !al16(ep.aux)) return false;
     if (epilogue == VITED_EPI_RESIDUAL && !al16(ep.residual)) return false;
     if (ceil_div64(M, 128) * ceil_div64(N, BN) > (1 << 30)) return false;
     return true;
@@ -210,6 +219,8 @@ int gemm_nt_mfma(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t
         case VITED_EPI_RESIDUAL: dispatch_nt<VITED_EPI_RESIDUAL>(a, lda, b, ldb, M, N, K, ep, s); break;
         case VITED_EPI_MUL_GELU_GRAD: dispatch_nt<VITED_EPI_MUL_GELU_GRAD>(a, lda, b, ldb, M, N, K, ep, s); break;
         case VITED_EPI_STORE_F32: dispatch_nt<VITED_EPI_STORE_F32>(a, lda, b, ldb, M, N, K, ep, s); break;
+        case VITED_EPI_MUL: dispatch_nt<VITED_EPI_MUL>(a, lda, b, ldb, M, N, K, ep, s); break;
+        case VITED_EPI_GELU_GRAD: dispatch_nt<VITED_EPI_GELU_GRAD>(a, lda, b, ldb, M, N, K, ep, s); break;
         default: return VITED_ERR_BAD_ARG;
     }
     return vited_check_launch();
@@ -223,16 +234,15 @@ int gemm_nt_mfma(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t
 // the slab leaves as 16-byte stores.  The bias gradient rides along: the workgroups of the first k-tile column
 // sum their dY fragments with v_dot2_f32_bf16 against packed ones (VALU, co-issued under the MFMAs).
 // ================================================================================================
-#ifndef TN_TM
-#define TN_TM 64
+// Two geometries of the same kernel (template parameters TM = m-rows per stage, STAGES = ring depth):
+//   <64, 2>  two 32 KB stages, 2 workgroups per CU, one stage in flight per workgroup (64 KB per CU); builtin LDS-DMA
+//   <32, 3>  three 16 KB stages, 3 workgroups per CU, TWO stages in flight per workgroup across the barrier (96 KB per CU):
+//            counted vmcnt + raw s_barrier, LDS-DMA from inline asm.  11-12 % faster on the 77-GFLOP shapes (dW fc1 / fc2:
+//            140 -> 123 us at M = 65,536), +-4 % on the others, so only those take it (gemm_tn_mfma_geometry).
+#ifndef TN_FORCE_TM          // -DTN_FORCE_TM=32 -DTN_FORCE_STAGES=3: one geometry for every shape (experiments)
+#define TN_FORCE_TM 0
+#define TN_FORCE_STAGES 0
 #endif
-#define TM TN_TM           // m-rows per stage: 64 (2 workgroups/CU) or 32 (3)
-#define TN_SLOTS (TM == 64 ? 512 : 768)
-#ifndef TN_STAGES
-#define TN_STAGES 2
-#endif
-#define T_TILE_BYTES (TM * 128 * 2)
-#define T_STAGE_BYTES (2 * T_TILE_BYTES)
 
 __device__ __forceinline__ int tn_f(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
 
@@ -240,9 +250,11 @@ __device__ __forceinline__ bf16x4 tr_read(const char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p);
 }
 
+template <int TM, bool ASM_DMA>
 __device__ __forceinline__ void tn_stage_load(const bf16* __restrict__ dY, int64_t lddy, const bf16* __restrict__ X,
                                               int64_t ldx, int64_t mrow0, int64_t mlast, int64_t n0, int64_t N,
                                               int64_t kc0, int64_t K, char* stage, int wave, int lane) {
+    constexpr int T_TILE_BYTES = TM * 128 * 2;
     const int rsub = lane >> 4, cp = lane & 15;
 #pragma unroll
     for (int i = 0; i < TM / 16; ++i) {
@@ -254,16 +266,23 @@ __device__ __forceinline__ void tn_stage_load(const bf16* __restrict__ dY, int64
         cn = cn <= N - 8 ? cn : N - 8;
         int64_t ck = kc0 + ch * 8;
         ck = ck <= K - 8 ? ck : K - 8;
-        glds16(dY + gm * lddy + cn, stage + (wave * (TM / 4) + i * 4) * 256);
-        glds16(X + gm * ldx + ck, stage + T_TILE_BYTES + (wave * (TM / 4) + i * 4) * 256);
+        if constexpr (ASM_DMA) {
+            glds16_asm(dY + gm * lddy + cn, stage + (wave * (TM / 4) + i * 4) * 256);
+            glds16_asm(X + gm * ldx + ck, stage + T_TILE_BYTES + (wave * (TM / 4) + i * 4) * 256);
+        } else {
+            glds16(dY + gm * lddy + cn, stage + (wave * (TM / 4) + i * 4) * 256);
+            glds16(X + gm * ldx + ck, stage + T_TILE_BYTES + (wave * (TM / 4) + i * 4) * 256);
+        }
     }
 }
 
-template <bool BIAS>
+template <bool BIAS, int TM, int TN_STAGES>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3)))   // 3 workgroups/CU: <= 168 VGPRs
 gemm_tn_mfma_kernel(const bf16* __restrict__ dY, int64_t lddy, const bf16* __restrict__ X, int64_t ldx, int64_t M, int64_t N,
                     int64_t K, int64_t rows_per_split, int tiles_k, float* __restrict__ out, float* __restrict__ bias_out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int T_TILE_BYTES = TM * 128 * 2, T_STAGE_BYTES = 2 * T_TILE_BYTES;
+    constexpr bool RING = TN_STAGES >= 3;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = wave >> 1, wc = wave & 1;
@@ -286,21 +305,27 @@ gemm_tn_mfma_kernel(const bf16* __restrict__ dY, int64_t lddy, const bf16* __res
     }
 
     const int nsteps = me > mb ? (int)((me - mb + TM - 1) / TM) : 0;
-    if (nsteps > 0) tn_stage_load(dY, lddy, X, ldx, mb, me - 1, n0, N, kc0, K, smem, wave, lane);
-#if TN_STAGES == 3
-    if (nsteps > 1) tn_stage_load(dY, lddy, X, ldx, mb + TM, me - 1, n0, N, kc0, K, smem + T_STAGE_BYTES, wave, lane);
-#endif
+    if (nsteps > 0) tn_stage_load<TM, RING>(dY, lddy, X, ldx, mb, me - 1, n0, N, kc0, K, smem, wave, lane);
+    if constexpr (RING) {
+#pragma unroll
+        for (int pre = 1; pre < TN_STAGES - 1; ++pre)
+            if (nsteps > pre) tn_stage_load<TM, RING>(dY, lddy, X, ldx, mb + pre * TM, me - 1, n0, N, kc0, K, smem + pre * T_STAGE_BYTES, wave, lane);
+    }
     const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
     for (int t = 0; t < nsteps; ++t) {
-#if TN_STAGES == 3
-        // three-slot ring: stage t + 1 stays in flight across the barrier (counted vmcnt, raw s_barrier)
-        if (t + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (TM / 16)) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        char* st = smem + (t % 3) * T_STAGE_BYTES;
-#else
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        char* st = smem + (t & 1) * T_STAGE_BYTES;
-#endif
+        // S-slot ring (S >= 3): stages t + 1 .. t + S - 2 stay in flight across the barrier (counted vmcnt, raw s_barrier; the DMA is
+        // issued from inline asm, see glds16_asm)
+        if constexpr (RING) {
+            constexpr int PER = 2 * (TM / 16);          // DMA instructions per stage per wave
+            const int ahead = nsteps - 1 - t;            // stages issued after stage t
+            if (ahead >= TN_STAGES - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((TN_STAGES - 2) * PER) : "memory");
+            else if (ahead == 2 && TN_STAGES > 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
+            else if (ahead == 1 && TN_STAGES > 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        char* st = smem + (t % TN_STAGES) * T_STAGE_BYTES;
         const int64_t mrow0 = mb + (int64_t)t * TM;
         if (mrow0 + TM > me) {  // ragged last stage: zero the rows this lane's DMA clamped
             const int rsub = lane >> 4, cp = lane & 15;
@@ -313,17 +338,16 @@ gemm_tn_mfma_kernel(const bf16* __restrict__ dY, int64_t lddy, const bf16* __res
                 }
             }
         }
-#if TN_STAGES == 3
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();   // stage t landed for every wave; everyone is done reading stage t - 1
-        asm volatile("" ::: "memory");
-        if (t + 2 < nsteps)
-            tn_stage_load(dY, lddy, X, ldx, mrow0 + 2 * TM, me - 1, n0, N, kc0, K, smem + ((t + 2) % 3) * T_STAGE_BYTES, wave, lane);
-#else
-        __syncthreads();
-        if (t + 1 < nsteps)
-            tn_stage_load(dY, lddy, X, ldx, mrow0 + TM, me - 1, n0, N, kc0, K, smem + ((t + 1) & 1) * T_STAGE_BYTES, wave, lane);
-#endif
+        if constexpr (RING) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();   // stage t landed for every wave; everyone is done reading stage t - 1
+            asm volatile("" ::: "memory");
+        } else {
+            __syncthreads();
+        }
+        if (t + TN_STAGES - 1 < nsteps)
+            tn_stage_load<TM, RING>(dY, lddy, X, ldx, mrow0 + (TN_STAGES - 1) * TM, me - 1, n0, N, kc0, K,
+                                    smem + ((t + TN_STAGES - 1) % TN_STAGES) * T_STAGE_BYTES, wave, lane);
         const char* sy = st;
         const char* sx = st + T_TILE_BYTES;
 #ifdef TN_DBG_DMA_ONLY
@@ -410,29 +434,60 @@ bool gemm_tn_mfma_supported(const void* dY, int64_t lddy, const void* X, int64_t
     return N % 8 == 0 && K % 8 == 0 && N >= 8 && K >= 8 && lddy % 8 == 0 && ldx % 8 == 0 && al16(dY) && al16(X) && M >= 1;
 }
 
-// Splits over M: as many as fill the chip's 512 resident workgroup slots (2 per CU at 64 KB of LDS)
+// Geometry per shape: the three-stage ring pays on the largest shapes only (measured, see the comment above the kernel).
+static inline bool tn_use_ring(int64_t M, int64_t N, int64_t K) {
+    if (TN_FORCE_TM) return TN_FORCE_STAGES >= 3;
+    static const char* env = getenv("VITED_TN_RING");          // tuning override: 0 = never, 1 = always
+    if (env) return atoi(env) != 0;
+    return N * K >= 1536 * 384 && M >= 16384;
+}
+
+// Splits over M: as many as fill the chip's resident workgroup slots (2 per CU at 64 KB of LDS, 3 per CU at 48 KB)
 // in ONE round - one workgroup more than a round costs a whole extra round.
 int64_t gemm_tn_mfma_splits(int64_t M, int64_t N, int64_t K) {
+    const bool ring = tn_use_ring(M, N, K);
+    const int tm = TN_FORCE_TM ? TN_FORCE_TM : (ring ? 32 : 64);
     const int64_t tiles = ceil_div64(N, 128) * ceil_div64(K, 128);
-    static const int64_t slots = getenv("VITED_TN_SLOTS") ? atoi(getenv("VITED_TN_SLOTS")) : TN_SLOTS;   // tuning override
+    static const int64_t slots_env = getenv("VITED_TN_SLOTS") ? atoi(getenv("VITED_TN_SLOTS")) : 0;   // tuning override
+    const int64_t slots = slots_env ? slots_env : (tm == 64 ? 512 : 768);
     int64_t s = slots / tiles;
     const int64_t max_s = ceil_div64(M, 512);
     if (s > max_s) s = max_s;
     if (s < 1) s = 1;
-    const int64_t rps = ceil_div64(ceil_div64(M, s), TM) * TM;
+    const int64_t rps = ceil_div64(ceil_div64(M, s), tm) * tm;
     return ceil_div64(M, rps);
+}
+
+template <int TM, int STAGES>
+static void launch_tn(const void* dY, int64_t lddy, const void* X, int64_t ldx, int64_t M, int64_t N, int64_t K, int64_t splits,
+                      float* out, float* bias_out, hipStream_t s) {
+    constexpr int LDS = STAGES * 2 * TM * 128 * 2;
+    const int tiles_k = (int)ceil_div64(K, 128);
+    const int tiles = (int)ceil_div64(N, 128) * tiles_k;
+    const int64_t rps = ceil_div64(ceil_div64(M, splits), TM) * TM;
+    if (LDS > 65536) {   // dynamic LDS above 64 KB needs the opt-in (once per kernel)
+        static bool done = false;
+        if (!done) {
+            hipFuncSetAttribute((const void*)gemm_tn_mfma_kernel<true, TM, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+            hipFuncSetAttribute((const void*)gemm_tn_mfma_kernel<false, TM, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+            done = true;
+        }
+    }
+    if (bias_out)
+        hipLaunchKernelGGL((gemm_tn_mfma_kernel<true, TM, STAGES>), dim3(tiles, (unsigned)splits), dim3(256), LDS, s,
+                           (const bf16*)dY, lddy, (const bf16*)X, ldx, M, N, K, rps, tiles_k, out, bias_out);
+    else
+        hipLaunchKernelGGL((gemm_tn_mfma_kernel<false, TM, STAGES>), dim3(tiles, (unsigned)splits), dim3(256), LDS, s,
+                           (const bf16*)dY, lddy, (const bf16*)X, ldx, M, N, K, rps, tiles_k, out, bias_out);
 }
 
 int gemm_tn_mfma(const void* dY, int64_t lddy, const void* X, int64_t ldx, int64_t M, int64_t N, int64_t K, int64_t splits,
                  float* out, float* bias_out, hipStream_t s) {
-    const int tiles_k = (int)ceil_div64(K, 128);
-    const int tiles = (int)ceil_div64(N, 128) * tiles_k;
-    const int64_t rps = ceil_div64(ceil_div64(M, splits), TM) * TM;
-    if (bias_out)
-        hipLaunchKernelGGL((gemm_tn_mfma_kernel<true>), dim3(tiles, (unsigned)splits), dim3(256), TN_STAGES * T_STAGE_BYTES, s,
-                           (const bf16*)dY, lddy, (const bf16*)X, ldx, M, N, K, rps, tiles_k, out, bias_out);
-    else
-        hipLaunchKernelGGL((gemm_tn_mfma_kernel<false>), dim3(tiles, (unsigned)splits), dim3(256), TN_STAGES * T_STAGE_BYTES, s,
-                           (const bf16*)dY, lddy, (const bf16*)X, ldx, M, N, K, rps, tiles_k, out, bias_out);
+#if TN_FORCE_TM
+    launch_tn<TN_FORCE_TM, TN_FORCE_STAGES>(dY, lddy, X, ldx, M, N, K, splits, out, bias_out, s);
+#else
+    if (tn_use_ring(M, N, K)) launch_tn<32, 3>(dY, lddy, X, ldx, M, N, K, splits, out, bias_out, s);
+    else launch_tn<64, 2>(dY, lddy, X, ldx, M, N, K, splits, out, bias_out, s);
+#endif
     return vited_check_launch();
 }

@@ -26,7 +26,7 @@ template <int EPI> struct EpiTraits {
 
 template <int EPI> struct EpiPrefetch {
     f32x4 res[EPI == VITED_EPI_RESIDUAL ? 4 : 1][4];          // [sub-tile][piece]
-    bf16x8 aux[EPI == VITED_EPI_MUL_GELU_GRAD ? 4 : 1][2];    // [sub-tile][piece]
+    bf16x8 aux[(EPI == VITED_EPI_MUL_GELU_GRAD || EPI == VITED_EPI_MUL) ? 4 : 1][2];    // [sub-tile][piece]
     f32x4 bias[2];                                            // this lane's 4 or 8 columns
 };
 
@@ -66,7 +66,7 @@ __device__ __forceinline__ void epilogue_prefetch_subtile(const EpiParams& p, Ep
             pf.res[i][pc] = (m < M && ncol) ? *(const f32x4*)(p.residual + rrow * p.ldo + n) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
-    if constexpr (EPI == VITED_EPI_MUL_GELU_GRAD) {
+    if constexpr (EPI == VITED_EPI_MUL_GELU_GRAD || EPI == VITED_EPI_MUL) {
 #pragma unroll
         for (int pc = 0; pc < 2; ++pc) {
             const int64_t m = mtile + i * 16 + T::row(lane, pc);
@@ -119,6 +119,23 @@ __device__ __forceinline__ void epilogue_subtile(const EpiParams& p, const EpiPr
             if constexpr (EPI == VITED_EPI_MUL_GELU_GRAD) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_fast((float)pf.aux[i][pc][e]);
+            }
+            if constexpr (EPI == VITED_EPI_MUL) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= (float)pf.aux[i][pc][e];
+            }
+            if constexpr (EPI == VITED_EPI_GELU_GRAD) {
+                bf16x8 pd, pg;     // one exponential serves both: exp(-z^2/2) is the Gaussian density AND the erfc tail
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float cdf, ex;
+                    gelu_parts_fast(v[e], cdf, ex);
+                    pd[e] = (bf16)fmaf(v[e] * 0.39894228040143268f, ex, cdf);
+                    pg[e] = (bf16)(v[e] * cdf);
+                }
+                *(bf16x8*)((bf16*)p.out + m * p.ldo + n) = pd;
+                *(bf16x8*)((bf16*)p.out2 + m * p.ldo + n) = pg;
+                continue;
             }
             bf16x8 pk;
 #pragma unroll

@@ -91,6 +91,8 @@ static int dispatch_portable(const void* A, int64_t lda, const void* B, int64_t 
         case VITED_EPI_RESIDUAL: launch_portable<T, VITED_EPI_RESIDUAL>(A, lda, B, ldb, b_layout, M, N, K, ep, s); break;
         case VITED_EPI_MUL_GELU_GRAD: launch_portable<T, VITED_EPI_MUL_GELU_GRAD>(A, lda, B, ldb, b_layout, M, N, K, ep, s); break;
         case VITED_EPI_STORE_F32: launch_portable<T, VITED_EPI_STORE_F32>(A, lda, B, ldb, b_layout, M, N, K, ep, s); break;
+        case VITED_EPI_MUL: launch_portable<T, VITED_EPI_MUL>(A, lda, B, ldb, b_layout, M, N, K, ep, s); break;
+        case VITED_EPI_GELU_GRAD: launch_portable<T, VITED_EPI_GELU_GRAD>(A, lda, B, ldb, b_layout, M, N, K, ep, s); break;
         default: return VITED_ERR_BAD_ARG;
     }
     return vited_check_launch();

@@ -303,6 +303,10 @@ class TrainStep:
         self.num_updates = 0
         self.last_norm = None
         self._lr_tensors = None
+        # a torch optimizer built with capturable=True reads its learning rate from a device scalar: keep it there in eager
+        # mode too, so eager and replayed updates see the same (fp32) value
+        self._tensor_lr = (not self.hip_opt) and all(g.get('capturable', False) for g in optimizer.param_groups) \
+            and next(model.parameters()).is_cuda
         self.device_type = 'cuda' if next(model.parameters()).is_cuda else 'cpu'
 
     # -- learning rate -----------------------------------------------------------------------
@@ -319,7 +323,7 @@ class TrainStep:
         if self.hip_opt:
             self.optimizer.sync_hyperparameters()
             return
-        if not self.use_graph:
+        if not self._tensor_lr:
             return
         if self._lr_tensors is None:
             dev = next(self.model.parameters()).device
@@ -413,7 +417,7 @@ class TrainStep:
 
     def _eager(self, x, y, last):
         buckets = self.flat.buckets()
-        if self.split and x.dim() == 5:
+        if self.split and torch.is_tensor(x) and x.dim() == 5:
             loss, feats, dfeats = self._fwd_dec_bwd(x, y)
             if last and len(buckets) == 2:
                 self.flat.start_all_reduce(*buckets[0], group=self.group)
@@ -436,13 +440,15 @@ class TrainStep:
 
     def _capture(self, x, y):
         from . import ops
+        if not torch.is_tensor(x):
+            raise TypeError('TrainStep(use_graph=True) replays on a static input tensor: pass use_graph=False for structured batches')
         self._static_x, self._static_y = x.clone(), y.clone()
         self._sync_lr()
         torch.cuda.synchronize()
         ops.pin_workspace()               # captured kernels bake buffer addresses in: later growth must not free them
         for rt in getattr(self.model, '_runtimes', {}).values():
             rt.pinned = True
-        split = self.split and x.dim() == 5
+        split = self.split and torch.is_tensor(x) and x.dim() == 5
         self._g1 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._g1):
             if split:

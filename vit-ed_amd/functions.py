@@ -17,7 +17,7 @@ from __future__ import annotations
 import torch
 
 from . import ops
-from ._lib import (B_KN, B_NK, EPI_GELU, EPI_MUL_GELU_GRAD, EPI_RESIDUAL, EPI_STORE, EPI_STORE_F32)
+from ._lib import (B_KN, B_NK, EPI_GELU_GRAD, EPI_MUL, EPI_RESIDUAL, EPI_STORE, EPI_STORE_F32)
 
 LN_EPS = 1e-6  # partial(nn.LayerNorm, eps=1e-6), vision_transformer.py:348
 
@@ -47,6 +47,7 @@ class Runtime:
         self.scale = self.head_dim ** -0.5
         self.act_dtype = act_dtype
         self.direct_grads = False   # accumulate parameter gradients straight into existing p.grad (engine.FlatGradients)
+        self.tap = None             # test/diagnostic: a dict that receives clones of per-block activations and gradients
         self.pinned = False         # a captured hipGraph reads the shadow buffers: never free one, only refresh in place
         self._retired = []
         self._shadow = {}
@@ -158,7 +159,7 @@ def _linear_bwd(rt, dy, x_saved, w, b=None, want_dx=True, aux=None):
     if want_dx:
         wt, layout = rt.weight_t(w)
         if aux is not None:
-            dx = ops.gemm(dy, wt, b_layout=layout, epilogue=EPI_MUL_GELU_GRAD, aux=aux)
+            dx = ops.gemm(dy, wt, b_layout=layout, epilogue=EPI_MUL, aux=aux)
         else:
             dx = ops.gemm(dy, wt, b_layout=layout)
     dw, db = _weight_grads(rt, dy, x_saved, w, b)
@@ -186,14 +187,15 @@ def _self_attn_bwd(rt, do, qkv, o, lse, batch, n):
 
 def _mlp_fwd(rt, x, g, b, w1, b1, w2, b2):
     h, mean, rstd = ops.layernorm_fwd(x, g, b, LN_EPS, rt.act_dtype)
-    z, u = ops.gemm(h, rt.weight(w1), epilogue=EPI_GELU, bias=b1)
+    # fc1 saves gelu'(z) and gelu(z) (one exponential serves both): the backward of the activation is then one multiply
+    gd, u = ops.gemm(h, rt.weight(w1), epilogue=EPI_GELU_GRAD, bias=b1)
     y = ops.gemm(u, rt.weight(w2), epilogue=EPI_RESIDUAL, bias=b2, residual=x)
-    return y, (mean, rstd, h, z, u)
+    return y, (mean, rstd, h, gd, u)
 
 
 def _mlp_bwd(rt, dy, dy_lp, x, g, b, w1, b1, w2, b2, saved):
-    mean, rstd, h, z, u = saved
-    dz, dw2, db2 = _linear_bwd(rt, dy_lp, u, w2, b2, aux=z)
+    mean, rstd, h, gd, u = saved
+    dz, dw2, db2 = _linear_bwd(rt, dy_lp, u, w2, b2, aux=gd)
     dh, dw1, db1 = _linear_bwd(rt, dz, h, w1, b1)
     dx, dx_lp, dg, db = _ln_bwd(rt, dh, x, g, b, mean, rstd, dx_in=dy, want_lp=not rt.exact)
     return dx, (dx if rt.exact else dx_lp), (dg, db, dw1, db1, dw2, db2)
@@ -268,6 +270,8 @@ class EncoderFn(torch.autograd.Function):
             if grad:
                 tape.append((x, sa, xa, sm))
             x = xb
+            if rt.tap is not None:
+                rt.tap[f'enc.x.{len(tape) - 1 if grad else 0}'] = x.clone()
         if grad:
             ctx.rt, ctx.tape, ctx.patches, ctx.batch, ctx.params = rt, tape, patches, batch, params
         return x.view(batch, n, rt.dim)
@@ -287,6 +291,8 @@ class EncoderFn(torch.autograd.Function):
             ctx.tape[i] = None
             dx, dx_lp, (dg2, db2, dw1, dbb1, dw2, dbb2) = _mlp_bwd(rt, dx, dx_lp, xa, g2, b2, w1, bb1, w2, bb2, sm)
             dx, dx_lp, (dg1, db1, dwq, dbq, dwp, dbp) = _attn_branch_bwd(rt, dx, dx_lp, x, g1, b1, wqkv, bqkv, wproj, bproj, sa, batch, n)
+            if rt.tap is not None:
+                rt.tap[f'enc.dx.{i}'] = dx.clone()      # gradient w.r.t. the INPUT of encoder block i
             base = 3 + i * nb
             blk = [dg1, db1, dwq, dbq, dwp, dbp, dg2, db2, dw1, dbb1, dw2, dbb2]
             grads[base: base + nb] = blk
@@ -328,6 +334,8 @@ class DecoderFn(torch.autograd.Function):
             if grad:
                 tape.append((x, sa, xa, (mq, rq, hq, mc, rc, hc, q, kv, oc, lse_c), xb, sm))
             x = xc
+            if rt.tap is not None:
+                rt.tap[f'dec.x.{len(tape) - 1 if grad else 0}'] = x.clone()
         # final norm on the cls rows only (LayerNorm is row-wise; only x[:, 0] reaches the head, :400,:417)
         x3 = x.view(batch, n, d)
         y, mN, rN = ops.layernorm_fwd(x3[:, 0, :], gN, bN, LN_EPS, rt.act_dtype)
@@ -379,6 +387,9 @@ class DecoderFn(torch.autograd.Function):
             ops.attention_bwd(q.view(batch, n, d), kv3[:, :, 0:d], kv3[:, :, d:2 * d], oc.view(batch, n, d),
                               doc.view(batch, n, d), lse_c, rt.heads, rt.scale, dq.view(batch, n, d), dkv3[:, :, 0:d],
                               dkv3[:, :, d:2 * d])
+            if rt.tap is not None:
+                rt.tap[f'dec.doc.{i}'], rt.tap[f'dec.dq.{i}'], rt.tap[f'dec.dkv.{i}'] = doc.clone(), dq.clone(), dkv.clone()
+                rt.tap[f'dec.q.{i}'], rt.tap[f'dec.kv.{i}'], rt.tap[f'dec.oc.{i}'] = q.clone(), kv.clone(), oc.clone()
             dhq, dwq, dbq = _linear_bwd(rt, dq, hq, wq, bq)
             dhc, dwkv, dbkv = _linear_bwd(rt, dkv, hc, wkv, bkv)
             dx, dx_lp, dgc, dbc = _ln_bwd(rt, dhq, xa, gc, bc, mq, rq, dx_in=dx, want_lp=not rt.exact)
@@ -387,6 +398,9 @@ class DecoderFn(torch.autograd.Function):
             # d(context) accumulates over the c_depth blocks in fp32, in place
             dctx, _, dgx, dbx = _ln_bwd(rt, dhc, ctx.ctxf, gx, bx, mc, rc, dx_in=dctx, dx_out=dctx)
             dx, dx_lp, (dg1, db1, dwqkv, dbqkv, dwp, dbp) = _attn_branch_bwd(rt, dx, dx_lp, x, g1, b1, wqkv, bqkv, wproj, bproj, sa, batch, n)
+            if rt.tap is not None:
+                rt.tap[f'dec.dx.{i}'] = dx.clone()      # gradient w.r.t. the INPUT of decoder block i
+                rt.tap[f'dec.dctx.{i}'] = dctx.clone()  # running d(features) after blocks c_depth-1 .. i
             base = ns + i * nb
             grads[base: base + nb] = [dg1, db1, dwqkv, dbqkv, dwp, dbp, dgc, dbc, dgx, dbx, dwq, dbq, dwkv, dbkv, dwcp, dbcp,
                                       dg2, db2, dw1, dbb1, dw2, dbb2]

@@ -242,11 +242,17 @@ class VisionTransformerCustom(nn.Module):
         feats = self.forward_first_part(x[:, 0])      # strided views: the kernels take a batch stride
         return self.forward_second_part_head(feats, x[:, 1])
 
-    def flops(self, batch=1):
-        """Algorithmic forward FLOPs per pair (2MNK per contraction)."""
+    def flops_parts(self):
+        """Algorithmic forward FLOPs (2MNK per contraction) of (the encoder on ONE image incl. its
+        patch embedding, the decoder + head on ONE pair incl. image 2's patch embedding)."""
         d, n1 = self.embed_dim, self.patch_embed.num_patches
         n2 = n1 + 1
         kp = self.in_chans * self.patch_size ** 2
         enc = self.depth * (24 * n1 * d * d + 4 * n1 * n1 * d)
         dec = self.c_depth * (28 * n2 * d * d + 4 * n1 * d * d + 4 * n2 * n2 * d + 4 * n2 * n1 * d)
-        return batch * (2 * 2 * n1 * kp * d + enc + dec + 2 * d * self.num_classes)
+        return 2 * n1 * kp * d + enc, 2 * n1 * kp * d + dec + 2 * d * self.num_classes
+
+    def flops(self, batch=1):
+        """Algorithmic forward FLOPs per pair (one-shot forward on a stacked pair)."""
+        enc, dec = self.flops_parts()
+        return batch * (enc + dec)

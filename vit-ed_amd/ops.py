@@ -11,7 +11,7 @@ from __future__ import annotations
 import torch
 
 from . import _lib
-from ._lib import (B_KN, B_NK, BF16, EPI_GELU, EPI_MUL_GELU_GRAD, EPI_RESIDUAL, EPI_STORE, EPI_STORE_F32, F32)
+from ._lib import (B_KN, B_NK, BF16, EPI_GELU, EPI_GELU_GRAD, EPI_MUL, EPI_MUL_GELU_GRAD, EPI_RESIDUAL, EPI_STORE, EPI_STORE_F32, F32)
 
 _DT = {torch.float32: F32, torch.bfloat16: BF16}
 
@@ -177,15 +177,20 @@ def sum_rows(x: torch.Tensor) -> torch.Tensor:
 
 
 # ---------------------------------------------------------------------------------------------
-def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, out_dtype: torch.dtype):
-    """x fp32 [rows, dim] (row-strided ok) -> (y [rows, dim] out_dtype, mean, rstd)."""
+def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, out_dtype: torch.dtype, out=None):
+    """x fp32 [rows, dim] (row-strided ok) -> (y [rows, dim] out_dtype, mean, rstd).  ``out`` = (y, mean, rstd) pre-made
+    (e.g. row slices of larger tensors)."""
     _need_gpu(x, gamma, beta)
     assert x.dtype == torch.float32 and gamma.dtype == torch.float32 and beta.dtype == torch.float32
     ld = _rows2d(x)
     rows, dim = x.shape
-    y = torch.empty((rows, dim), dtype=out_dtype, device=x.device)
-    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
-    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    if out is not None:
+        y, mean, rstd = out
+        assert y.shape == (rows, dim) and y.dtype == out_dtype and _rows2d(y) == dim and mean.numel() == rows and rstd.numel() == rows
+    else:
+        y = torch.empty((rows, dim), dtype=out_dtype, device=x.device)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
     _lib.check(_lib.load().vited_layernorm_fwd(_ptr(x), ld, _ptr(gamma), _ptr(beta), _ptr(y), _code(out_dtype), dim,
                                                _ptr(mean), _ptr(rstd), rows, dim, float(eps), _stream()), 'vited_layernorm_fwd')
     return y, mean, rstd
@@ -227,7 +232,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dx_in=None, dx_out=None, want_lp: bo
 
 # ---------------------------------------------------------------------------------------------
 def gemm(a: torch.Tensor, b: torch.Tensor, *, b_layout: int = B_NK, epilogue: int = EPI_STORE, bias=None, aux=None,
-         residual=None, out=None, rows_per_batch: int = 0, out_rows_per_batch: int = 0, row_offset: int = 0,
+         residual=None, out=None, out2=None, rows_per_batch: int = 0, out_rows_per_batch: int = 0, row_offset: int = 0,
          residual_bcast: bool = False, out_rows: int | None = None):
     """acc = a[M,K] . (b[N,K]^T | b[K,N]); see VITED_EPI_* in include/vited.h.
 
@@ -245,9 +250,12 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, b_layout: int = B_NK, epilogue: in
         rows = m if out_rows is None else out_rows
         out = torch.empty((rows, n), dtype=torch.float32 if f32_out else a.dtype, device=a.device)
     ldo = _rows2d(out)
-    out2 = None
-    if epilogue == EPI_GELU:
-        out2 = torch.empty_like(out)
+    if epilogue in (EPI_GELU, EPI_GELU_GRAD):
+        if out2 is None:
+            out2 = torch.empty_like(out)
+        assert out2.dtype == out.dtype and out2.shape == out.shape and _rows2d(out2) == ldo
+    else:
+        out2 = None
     if aux is not None:
         assert aux.dtype == a.dtype and _rows2d(aux) == ldo
     if residual is not None:
@@ -259,7 +267,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, b_layout: int = B_NK, epilogue: in
         _ptr(a), lda, _ptr(b), ldb, b_layout, _code(a.dtype), m, n, k, epilogue, _ptr(bias), _ptr(aux), _ptr(residual),
         _ptr(out), _ptr(out2), ldo, rows_per_batch, out_rows_per_batch, row_offset, int(bool(residual_bcast)), _stream()),
         'vited_gemm')
-    return (out, out2) if epilogue == EPI_GELU else out
+    return (out, out2) if epilogue in (EPI_GELU, EPI_GELU_GRAD) else out
 
 
 def linear_bwd_weight(dy: torch.Tensor, x: torch.Tensor, want_bias: bool = True, dw_out=None, db_out=None):
@@ -284,6 +292,43 @@ def linear_bwd_weight(dy: torch.Tensor, x: torch.Tensor, want_bias: bool = True,
     _lib.check(lib.vited_linear_bwd_weight(_ptr(dy), lddy, _ptr(x), ldx, _code(x.dtype), m, n, k, _ptr(dw), _ptr(db),
                                            int(accumulate), _ptr(ws), ws.numel() * 4, _stream()), 'vited_linear_bwd_weight')
     return dw, db
+
+
+# ---------------------------------------------------------------------------------------------
+def mlp_fused_supported(x: torch.Tensor, w1: torch.Tensor) -> bool:
+    """The fused MLP kernel covers bf16, embed dim 384, hidden 1536 (every shipped pjs config)."""
+    return w1.dtype == torch.bfloat16 and tuple(w1.shape) == (1536, 384) and x.shape[-1] == 384
+
+
+def mlp_fwd(x, gamma, beta, w1, b1, w2, b2, eps: float, save: bool = True, out=None):
+    """y = x + fc2(gelu(fc1(LayerNorm(x)))) in one kernel (``vited_mlp_fwd``).  x fp32 [rows, 384]; w1 / w2 the bf16 weights.
+    Returns (y, saved) with saved = (mean, rstd, h, gd, u) or None.  ``out`` = (y, mean, rstd, h, gd, u) pre-made outputs
+    (row slices of larger tensors are fine for y; the others must be dense)."""
+    _need_gpu(x, gamma, beta, w1, b1, w2, b2)
+    assert x.dtype == torch.float32 and w1.dtype == w2.dtype == torch.bfloat16 and w1.is_contiguous() and w2.is_contiguous()
+    ldx = _rows2d(x)
+    rows, dim = x.shape
+    hidden = w1.shape[0]
+    assert w1.shape == (hidden, dim) and w2.shape == (dim, hidden)
+    dev = x.device
+    if out is not None:
+        y, mean, rstd, h, gd, u = out
+    else:
+        y = torch.empty((rows, dim), dtype=torch.float32, device=dev)
+        mean = rstd = h = gd = u = None
+        if save:
+            mean = torch.empty(rows, dtype=torch.float32, device=dev)
+            rstd = torch.empty(rows, dtype=torch.float32, device=dev)
+            h = torch.empty((rows, dim), dtype=torch.bfloat16, device=dev)
+            gd = torch.empty((rows, hidden), dtype=torch.bfloat16, device=dev)
+            u = torch.empty((rows, hidden), dtype=torch.bfloat16, device=dev)
+    if save:
+        assert h.is_contiguous() and gd.is_contiguous() and u.is_contiguous() and h.shape == (rows, dim) and gd.shape == u.shape == (rows, hidden)
+    _lib.check(_lib.load().vited_mlp_fwd(_ptr(x), ldx, _ptr(gamma), _ptr(beta), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(y), _rows2d(y),
+                                         _ptr(h) if save else 0, _ptr(gd) if save else 0, _ptr(u) if save else 0,
+                                         _ptr(mean) if save else 0, _ptr(rstd) if save else 0, rows, dim, hidden, float(eps), _stream()),
+               'vited_mlp_fwd')
+    return y, ((mean, rstd, h, gd, u) if save else None)
 
 
 # ---------------------------------------------------------------------------------------------
