@@ -89,6 +89,13 @@ int vited_cast_weights(const int64_t* desc, int count, int64_t total_tiles, void
 int vited_patchify(const float* img, int64_t img_bs, const int64_t* batch_index, void* out, int out_dtype,
                    int64_t batch, int chans, int img_size, int patch, void* stream);
 
+/* The same from uint8 pixels, with the input pipeline's ToTensor + Normalize(mean, std) (data/transforms.py:14-18, applied per
+ * sample on the host by the reference's loader, data/datasets/div2k_patch.py:108-162) folded in:
+ * value = (pixel / 255 - mean[c]) / std[c].  mean / std are HOST arrays of `chans` (<= 4) floats.  A batch then crosses PCIe and
+ * HBM at 1 byte per pixel (misc/engine.py:203-204 copies fp32). */
+int vited_patchify_u8(const uint8_t* img, int64_t img_bs, const int64_t* batch_index, void* out, int out_dtype,
+                      int64_t batch, int chans, int img_size, int patch, const float* mean, const float* std, void* stream);
+
 /* out[b, r] = (out_dtype) in[b, row_offset + r] for r < rows: drops the cls row of a token-gradient
  * tensor before the patch-embed weight gradient. in is fp32 [batch, in_rows, dim]. */
 int vited_slice_rows_cast(const float* in, void* out, int out_dtype, int64_t batch, int64_t in_rows,
@@ -193,6 +200,16 @@ int vited_attention_fwd(const void* q, int64_t q_bs, int64_t q_ts, const void* k
                         const void* v, int64_t v_bs, int64_t v_ts, void* o, int64_t o_bs, int64_t o_ts,
                         float* lse, int dtype, int64_t batch, int heads, int64_t nq, int64_t nk, int head_dim,
                         float scale, void* stream);
+
+/* The same with an indirection on the key/value side: batch item b attends over k / v of batch item kv_index[b]
+ * (kv_index: DEVICE int64 [batch], values in [0, number of k/v batch items); null = identity).  Serves the pairwise
+ * similarity-matrix inference (hisfrag.py:218-231): the cross-attention keys/values of an image-1 row block are projected
+ * ONCE and every (i, j) pair of a pair batch reads row i's - no materialised features[i] gather (hisfrag.py:227), no
+ * per-pair norm_context + kv projection (vision_transformer.py:174-179 re-runs them for every pair).  Forward only. */
+int vited_attention_fwd_indexed(const void* q, int64_t q_bs, int64_t q_ts, const void* k, int64_t k_bs, int64_t k_ts,
+                                const void* v, int64_t v_bs, int64_t v_ts, const int64_t* kv_index, void* o, int64_t o_bs,
+                                int64_t o_ts, float* lse, int dtype, int64_t batch, int heads, int64_t nq, int64_t nk,
+                                int head_dim, float scale, void* stream);
 
 /* dq/dk/dv in the same strided layouts; delta (fp32 [B, H, Nq]) is scratch for rowsum(dO * O). */
 int vited_attention_bwd(const void* q, int64_t q_bs, int64_t q_ts, const void* k, int64_t k_bs, int64_t k_ts,

@@ -266,6 +266,9 @@ def test_pairwise_similarity_matches_the_oracle(vited, gpu, dtype):
     n = 13
     imgs = torch.randn(n, 3, 256, 256, generator=g).clamp(-1, 1)
     sim = vited.engine.pairwise_similarity(model, imgs.to(gpu), block=5, pair_batch=64, amp=dtype == torch.bfloat16)
+    # the uncached form (features gathered per pair batch, image 2 re-embedded per pair: what hisfrag.py:226-229 does) agrees
+    plain = vited.engine.pairwise_similarity(model, imgs.to(gpu), block=5, pair_batch=64, amp=dtype == torch.bfloat16, pair_cache=False)
+    torch.testing.assert_close(sim.float(), plain.float(), rtol=1e-2, atol=1e-2)
     i, j = torch.triu_indices(n, n)
     with torch.no_grad():
         ref = oracle(torch.stack([imgs[i], imgs[j]], dim=1)).reshape(-1)
@@ -397,3 +400,27 @@ def test_train_step_graph_replay_matches_eager_steps_and_the_oracle(vited, gpu, 
         err = (pe.detach().cpu() - po[n].detach()).norm() / (po[n].detach().norm() + 1e-12)
         # AdamW's g / sqrt(v) update is scale-free, so it amplifies fp32 rounding differences of tiny gradients: 5e-3
         assert err < 5e-3, f'{n}: {err:.3e} vs the oracle after 5 AdamW steps'
+
+
+def test_uint8_inputs_and_prefetcher(vited, gpu):
+    """uint8 pixels go straight into the patch-embedding kernel (ToTensor + Normalize(0.5, 0.5) of
+    data/transforms.py:14-18 folded in) and ``engine.DevicePrefetcher`` copies batches one ahead on a side stream.  Same logits
+    as the reference pipeline's fp32 tensors; same batches, same order as the wrapped loader."""
+    s = vo.ViTEDShape(depth=1, c_depth=1)
+    model = vo.fill_closed_form_(_hip_model(vited, s, gpu, torch.float32))
+    g = torch.Generator().manual_seed(2)
+    batches = [(torch.randint(0, 256, (5, 2, 3, 64, 64), generator=g, dtype=torch.uint8), torch.rand(5, 4, generator=g)) for _ in range(5)]
+    as_float = lambda u8: (u8.float() / 255.0 - 0.5) / 0.5
+    with torch.no_grad():
+        want = [model(as_float(x).to(gpu)) for x, _ in batches]
+        got = []
+        for (x, y), (x0, y0) in zip(vited.engine.DevicePrefetcher(batches, gpu, depth=2), batches):
+            assert x.dtype == torch.uint8 and x.device.type == 'cuda' and torch.equal(x.cpu(), x0) and torch.equal(y.cpu(), y0)
+            got.append(model(x))
+    assert len(got) == len(want)
+    for a, b in zip(got, want):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5)
+    # op level: bit-equal to the fp32 patchify of the normalised image computed with the same fma
+    x = batches[0][0][:, 0].to(gpu)
+    ref = vited.ops.patchify(torch.addcmul(torch.full((5, 3, 64, 64), -1.0, device=gpu), x.float(), torch.full((1,), 1.0 / 127.5, device=gpu)), 8, torch.float32)
+    torch.testing.assert_close(vited.ops.patchify(x, 8, torch.float32), ref, rtol=0, atol=2e-7)

@@ -30,6 +30,7 @@ SIGNATURES = {
     'vited_cast_transpose': (_i, [_p, _p, _i, _i64, _i64, _p]),
     'vited_cast_weights': (_i, [_p, _i, _i64, _p]),
     'vited_patchify': (_i, [_p, _i64, _p, _p, _i, _i64, _i, _i, _i, _p]),
+    'vited_patchify_u8': (_i, [_p, _i64, _p, _p, _i, _i64, _i, _i, _i, _p, _p, _p]),
     'vited_slice_rows_cast': (_i, [_p, _p, _i, _i64, _i64, _i64, _i64, _i64, _p]),
     'vited_write_cls_row': (_i, [_p, _p, _p, _i64, _i64, _i64, _p]),
     'vited_sum_rows_workspace_bytes': (_i64, [_i64, _i64]),
@@ -47,6 +48,8 @@ SIGNATURES = {
     'vited_adamw_step': (_i, [_p, _i, _i64, _p, _i64, _p, _f, _i, _p, _p, _i64, _p]),
     'vited_attention_fwd': (_i, [_p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _p, _i, _i64, _i,
                                  _i64, _i64, _i, _f, _p]),
+    'vited_attention_fwd_indexed': (_i, [_p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _p, _p, _i64, _i64, _p, _i, _i64, _i,
+                                         _i64, _i64, _i, _f, _p]),
     'vited_attention_bwd': (_i, [_p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _p, _p, _i64, _i64, _p, _p,
                                  _p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _i, _i64, _i, _i64, _i64, _i, _f, _p]),
 }

@@ -17,8 +17,17 @@ extern "C" int vited_attention_fwd(const void* q, int64_t q_bs, int64_t q_ts, co
                                    const void* v, int64_t v_bs, int64_t v_ts, void* o, int64_t o_bs, int64_t o_ts,
                                    float* lse, int dtype, int64_t batch, int heads, int64_t nq, int64_t nk, int head_dim,
                                    float scale, void* stream) {
+    return vited_attention_fwd_indexed(q, q_bs, q_ts, k, k_bs, k_ts, v, v_bs, v_ts, nullptr, o, o_bs, o_ts, lse, dtype, batch, heads, nq,
+                                       nk, head_dim, scale, stream);
+}
+
+extern "C" int vited_attention_fwd_indexed(const void* q, int64_t q_bs, int64_t q_ts, const void* k, int64_t k_bs, int64_t k_ts,
+                                           const void* v, int64_t v_bs, int64_t v_ts, const int64_t* kv_index, void* o, int64_t o_bs,
+                                           int64_t o_ts, float* lse, int dtype, int64_t batch, int heads, int64_t nq, int64_t nk,
+                                           int head_dim, float scale, void* stream) {
     AttnArgs a = {};
     a.q = q; a.k = k; a.v = v;
+    a.kv_index = kv_index;
     a.q_bs = q_bs; a.q_ts = q_ts; a.k_bs = k_bs; a.k_ts = k_ts; a.v_bs = v_bs; a.v_ts = v_ts;
     a.o = o; a.o_bs = o_bs; a.o_ts = o_ts;
     a.lse = lse;

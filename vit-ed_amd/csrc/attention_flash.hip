@@ -81,8 +81,9 @@ attn_fwd_flash_kernel(AttnArgs a) {
     const int q0 = blockIdx.x * (64 * FL_W) + wave * (16 * FL_W);
     const int64_t hoff = (int64_t)h * HD;
     const bf16* qb = (const bf16*)a.q + b * a.q_bs + hoff;
-    const bf16* kb = (const bf16*)a.k + b * a.k_bs + hoff;
-    const bf16* vb = (const bf16*)a.v + b * a.v_bs + hoff;
+    const int64_t bkv = a.kv_index ? a.kv_index[b] : b;
+    const bf16* kb = (const bf16*)a.k + bkv * a.k_bs + hoff;
+    const bf16* vb = (const bf16*)a.v + bkv * a.v_bs + hoff;
     const float sc = a.scale * LOG2E;
 
     bf16x8 qf[FL_W][C::KCH];

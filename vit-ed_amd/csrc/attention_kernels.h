@@ -4,6 +4,7 @@
 
 struct AttnArgs {
     const void *q, *k, *v;
+    const int64_t* kv_index;   // forward only, nullable: batch item b reads k / v of batch item kv_index[b]
     int64_t q_bs, q_ts, k_bs, k_ts, v_bs, v_ts;
     const void* o;    // forward: output (written); backward: saved output
     const void* d_o;  // backward only

@@ -30,8 +30,9 @@ attn_fwd_small_kernel(AttnArgs a) {
     h = live ? h : a.heads - 1;
     const int nq = (int)a.nq, nk = (int)a.nk;
     const bf16* qb = (const bf16*)a.q + b * a.q_bs + (int64_t)h * HD;
-    const bf16* kb = (const bf16*)a.k + b * a.k_bs + (int64_t)h * HD;
-    const bf16* vb = (const bf16*)a.v + b * a.v_bs + (int64_t)h * HD;
+    const int64_t bkv = a.kv_index ? a.kv_index[b] : b;
+    const bf16* kb = (const bf16*)a.k + bkv * a.k_bs + (int64_t)h * HD;
+    const bf16* vb = (const bf16*)a.v + bkv * a.v_bs + (int64_t)h * HD;
     char* vs = smem + wave * C::TILE_BYTES;
     char* os = smem + 4 * C::TILE_BYTES + wave * 16 * C::ROW_BYTES;   // output scratch: one 16-row tile per wave
 

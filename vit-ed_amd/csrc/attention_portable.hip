@@ -32,8 +32,9 @@ attn_fwd_portable_kernel(AttnArgs a) {
     const int h = blockIdx.y;
     const int64_t i = (int64_t)blockIdx.x * AP_THREADS + threadIdx.x;
     const bool live = i < a.nq;
-    const T* kb = (const T*)a.k + b * a.k_bs + (int64_t)h * HD;
-    const T* vb = (const T*)a.v + b * a.v_bs + (int64_t)h * HD;
+    const int64_t bkv = a.kv_index ? a.kv_index[b] : b;
+    const T* kb = (const T*)a.k + bkv * a.k_bs + (int64_t)h * HD;
+    const T* vb = (const T*)a.v + bkv * a.v_bs + (int64_t)h * HD;
     float qr[HD], acc[HD];
 #pragma unroll
     for (int d = 0; d < HD; ++d) acc[d] = 0.f;

@@ -186,6 +186,56 @@ extern "C" int vited_patchify(const float* img, int64_t img_bs, const int64_t* b
 }
 
 // ------------------------------------------------------------------------------------------------
+// patchify straight from uint8 pixels: ToTensor + Normalize(mean, std) of the input pipeline (data/transforms.py:14-18) folded
+// into the patch extraction, so a batch crosses PCIe and HBM as 1 byte per pixel instead of 4.
+// value = pixel * scale[c] + shift[c] with scale = 1 / (255 std), shift = -mean / std.
+// ------------------------------------------------------------------------------------------------
+struct U8Norm { float scale[4], shift[4]; };
+
+template <typename D>
+__global__ void patchify_u8_kernel(const uint8_t* __restrict__ img, int64_t img_bs, const int64_t* __restrict__ bidx,
+                                   D* __restrict__ out, int chans, int S, int p, U8Norm nrm) {
+    const int G = S / p;
+    const int64_t b = blockIdx.y;
+    const int py = blockIdx.x;
+    const int64_t src_b = bidx ? bidx[b] : b;
+    const uint8_t* base = img + src_b * img_bs;
+    const int Kp = chans * p * p;
+    const int total = chans * p * S;  // elements in this strip: (c, i, x)
+    D* obase = out + (b * G * G + (int64_t)py * G) * Kp;
+    for (int e = threadIdx.x; e < total; e += blockDim.x) {
+        const int x = e % S;
+        const int ci = e / S;  // c * p + i
+        const int i = ci % p, c = ci / p;
+        const float v = fmaf((float)base[((int64_t)c * S + (py * p + i)) * S + x], nrm.scale[c], nrm.shift[c]);
+        const int px = x / p, j = x - px * p;
+        obase[(int64_t)px * Kp + (c * p + i) * p + j] = from_f32<D>(v);
+    }
+}
+
+extern "C" int vited_patchify_u8(const uint8_t* img, int64_t img_bs, const int64_t* batch_index, void* out, int out_dtype,
+                                 int64_t batch, int chans, int img_size, int patch, const float* mean, const float* std,
+                                 void* stream) {
+    if (!img || !out || !mean || !std || batch <= 0 || chans <= 0 || chans > 4 || img_size <= 0 || patch <= 0 || img_size % patch)
+        return VITED_ERR_BAD_ARG;
+    U8Norm nrm = {};
+    for (int c = 0; c < chans; ++c) {
+        if (!(std[c] > 0.f)) return VITED_ERR_BAD_ARG;
+        nrm.scale[c] = 1.0f / (255.0f * std[c]);
+        nrm.shift[c] = -mean[c] / std[c];
+    }
+    dim3 grid(img_size / patch, (unsigned)batch);
+    hipStream_t s = (hipStream_t)stream;
+    if (out_dtype == VITED_BF16)
+        hipLaunchKernelGGL((patchify_u8_kernel<bf16>), grid, dim3(256), 0, s, img, img_bs, batch_index, (bf16*)out, chans, img_size, patch, nrm);
+    else if (out_dtype == VITED_F32)
+        hipLaunchKernelGGL((patchify_u8_kernel<float>), grid, dim3(256), 0, s, img, img_bs, batch_index, (float*)out, chans, img_size, patch, nrm);
+    else
+        return VITED_ERR_UNSUPPORTED;
+    return vited_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------
 // slice rows + cast
 // ------------------------------------------------------------------------------------------------
 template <typename D>

@@ -465,6 +465,67 @@ class TrainStep:
 
 
 # ---------------------------------------------------------------------------------------------
+# input pipeline: host -> HBM one batch ahead (misc/engine.py:202-204)
+# ---------------------------------------------------------------------------------------------
+class DevicePrefetcher:
+    """Wraps a loader of (samples, targets) CPU batches.  The reference copies every batch on the compute stream at the top of
+    the iteration (``samples.cuda(non_blocking=True)``, misc/engine.py:203-204) as fp32.  Here the batch is staged in pinned host
+    memory and copied on a side stream ``depth`` batches ahead of the step that consumes it, and uint8 images stay uint8 all the
+    way into the patch-embedding kernel (``vited_patchify_u8`` applies ToTensor + Normalize), so a config-A batch of 1024 pairs
+    is 25 MB on PCIe instead of 101 MB.  Yields device tensors; iteration order and contents equal the wrapped loader's."""
+
+    def __init__(self, loader, device, depth: int = 2):
+        self.loader, self.device, self.depth = loader, torch.device(device), max(int(depth), 1)
+        self.stream = torch.cuda.Stream(device=self.device) if self.device.type == 'cuda' else None
+        self._pinned = {}
+
+    def __len__(self):
+        return len(self.loader)
+
+    def _stage(self, t, slot, name):
+        """CPU tensor -> device tensor through a reusable pinned buffer (per ring slot), on the copy stream."""
+        if not torch.is_tensor(t):
+            return t
+        if self.stream is None:
+            return t.to(self.device)
+        key = (slot, name, tuple(t.shape), t.dtype)
+        buf = self._pinned.get(key)
+        if buf is None:
+            buf = self._pinned[key] = torch.empty(t.shape, dtype=t.dtype).pin_memory()
+        buf.copy_(t)
+        return buf.to(self.device, non_blocking=True)
+
+    def __iter__(self):
+        import collections
+        queue = collections.deque()
+        slot = 0
+        for batch in self.loader:
+            samples, targets = batch
+            if self.stream is not None:
+                with torch.cuda.stream(self.stream):
+                    item = (self._stage(samples, slot, 'x'), self._stage(targets, slot, 'y'))
+                    ev = torch.cuda.Event()
+                    ev.record(self.stream)
+            else:
+                item, ev = (self._stage(samples, slot, 'x'), self._stage(targets, slot, 'y')), None
+            queue.append((item, ev))
+            slot = (slot + 1) % (self.depth + 1)          # a pinned buffer is rewritten only after its batch was handed out
+            if len(queue) > self.depth:
+                yield self._hand_out(*queue.popleft())
+        while queue:
+            yield self._hand_out(*queue.popleft())
+
+    def _hand_out(self, item, ev):
+        if ev is not None:
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(ev)                              # the consumer's stream waits for the copy, the host does not
+            for t in item:
+                if torch.is_tensor(t):
+                    t.record_stream(cur)
+        return item
+
+
+# ---------------------------------------------------------------------------------------------
 # pair mining for the two-stage HisFrag training step (hisfrag.py:117-159, SURVEY.md section 8(f) rank 3)
 # ---------------------------------------------------------------------------------------------
 def mine_pairs(targets: torch.Tensor, neg_per_pos: float = 2.0, generator=None):
@@ -518,7 +579,7 @@ def shard_rows_by_pair_count(n: int, world: int):
 
 @torch.no_grad()
 def pairwise_similarity(model, images, *, rank: int = 0, world: int = 1, block: int = 64, pair_batch: int = 512,
-                        amp: bool = True, group=None):
+                        amp: bool = True, group=None, pair_cache: bool = True):
     """similarity[i, j] = similarity[j, i] = fp16(logit(model(features(image_i), image_j))) for i <= j.
 
     What hisfrag.py:161-302 computes, re-plumbed: the encoder runs ONCE per image of this rank's row
@@ -533,18 +594,28 @@ def pairwise_similarity(model, images, *, rank: int = 0, world: int = 1, block: 
     r0, r1 = bounds[rank], bounds[rank + 1]
     dtype_ctx = torch.autocast(dev.type, dtype=torch.bfloat16, enabled=amp)
     by_index = bool(getattr(model, 'supports_x2_index', False))
+    # pair cache (HIP model): image-2 tokens once per image, cross-attention K / V once per row block, both read by index
+    cached = bool(getattr(model, 'supports_pair_cache', False)) and pair_cache and r1 > r0
     scores = []
     was_training = model.training
     model.eval()
+    tokens2 = None
+    if cached:
+        with dtype_ctx:
+            lo = r0                                                        # this rank only ever needs images j >= its first row
+            tokens2 = torch.cat([model.cache_image2_tokens(images[c:min(c + 256, n)]) for c in range(lo, n, 256)])
     for a0 in range(r0, r1, block):
         a1 = min(a0 + block, r1)
         with dtype_ctx:
             feats = model(images[a0:a1], forward_first_part=True)          # encoder once per row block
+            kvs = model.cache_context_kv(feats) if cached else None
         ii, jj = torch.triu_indices(a1 - a0, n - a0, offset=0, device=dev)  # pairs (a0+ii, a0+jj), jj >= ii
         for c0 in range(0, ii.numel(), pair_batch):
             i_sub, j_sub = ii[c0:c0 + pair_batch], (jj[c0:c0 + pair_batch] + a0)
             with dtype_ctx:
-                if by_index:
+                if cached:
+                    out = model.forward_pairs_cached(tokens2, j_sub - r0, kvs, i_sub)
+                elif by_index:
                     out = model(feats[i_sub], images, x2_index=j_sub)
                 else:
                     out = model(feats[i_sub], images[j_sub])

@@ -14,6 +14,8 @@ exact path).
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import ops
@@ -47,6 +49,8 @@ class Runtime:
         self.scale = self.head_dim ** -0.5
         self.act_dtype = act_dtype
         self.direct_grads = False   # accumulate parameter gradients straight into existing p.grad (engine.FlatGradients)
+        self.input_mean, self.input_std = (0.5, 0.5, 0.5), (0.5, 0.5, 0.5)   # Normalize() of data/transforms.py:14-18, for uint8 inputs
+        self.fused_mlp = os.environ.get('VITED_FUSED_MLP', '1') != '0'   # vited_mlp_fwd on the no-grad paths
         self.tap = None             # test/diagnostic: a dict that receives clones of per-block activations and gradients
         self.pinned = False         # a captured hipGraph reads the shadow buffers: never free one, only refresh in place
         self._retired = []
@@ -185,7 +189,38 @@ def _self_attn_bwd(rt, do, qkv, o, lse, batch, n):
     return dqkv
 
 
-def _mlp_fwd(rt, x, g, b, w1, b1, w2, b2):
+FUSED_MLP_TILE = 128        # token rows per workgroup of vited_mlp_fwd (one workgroup per CU)
+FUSED_MLP_CUS = 256
+
+
+def _fused_mlp_rows(rt, x, w1, grad):
+    """How many leading rows the fused MLP kernel (vited_mlp_fwd) takes: it runs one 128-row workgroup per CU, so a last
+    round that fills less than a quarter of the chip is left to the unfused kernels (66,560 rows = 520 tiles = 2 rounds + 8
+    tiles: the 8 tiles would cost a third round).  0 = do not use it.  Measured (profiles/mlp_probe.py, M = 65,536): it beats
+    LayerNorm + fc1/GELU + fc2/residual when nothing is saved for backward (312 vs 347 us) and loses when the backward's
+    operands must be written (379 us), so it serves the no-grad paths (evaluation, similarity-matrix inference)."""
+    if grad or rt.exact or not rt.fused_mlp or x.shape[1] != 384 or tuple(w1.shape) != (1536, 384) or x.stride(0) != 384:
+        return 0
+    tiles = x.shape[0] // FUSED_MLP_TILE
+    rem = tiles % FUSED_MLP_CUS
+    if tiles >= FUSED_MLP_CUS and rem < FUSED_MLP_CUS // 4:
+        tiles -= rem
+    elif x.shape[0] % FUSED_MLP_TILE:
+        tiles += 1                      # ragged last tile: the kernel clamps rows
+    return min(tiles * FUSED_MLP_TILE, x.shape[0])
+
+
+def _mlp_fwd(rt, x, g, b, w1, b1, w2, b2, grad=True):
+    rows = _fused_mlp_rows(rt, x, w1, grad)
+    if rows:
+        y = torch.empty_like(x)
+        ops.mlp_fwd(x[:rows], g, b, rt.weight(w1), b1, rt.weight(w2), b2, LN_EPS, save=False, out=(y[:rows], None, None, None, None, None))
+        if rows < x.shape[0]:
+            xt = x[rows:]
+            ht, _, _ = ops.layernorm_fwd(xt, g, b, LN_EPS, rt.act_dtype)
+            _, ut = ops.gemm(ht, rt.weight(w1), epilogue=EPI_GELU_GRAD, bias=b1)
+            ops.gemm(ut, rt.weight(w2), epilogue=EPI_RESIDUAL, bias=b2, residual=xt, out=y[rows:])
+        return y, None
     h, mean, rstd = ops.layernorm_fwd(x, g, b, LN_EPS, rt.act_dtype)
     # fc1 saves gelu'(z) and gelu(z) (one exponential serves both): the backward of the activation is then one multiply
     gd, u = ops.gemm(h, rt.weight(w1), epilogue=EPI_GELU_GRAD, bias=b1)
@@ -219,7 +254,7 @@ def _attn_branch_bwd(rt, dy, dy_lp, x, g, b, wqkv, bqkv, wproj, bproj, saved, ba
 
 def _patch_tokens_fwd(rt, img, pw, pb, pos, with_cls, cls=None, batch_index=None):
     """timm PatchEmbed + pos-embed (+ cls row): returns x fp32 [B*rows, D] and the saved patch matrix."""
-    patches = ops.patchify(img, rt.patch_size, rt.act_dtype, batch_index)
+    patches = ops.patchify(img, rt.patch_size, rt.act_dtype, batch_index, mean=rt.input_mean, std=rt.input_std)
     batch = patches.shape[0] // rt.n1
     pos2 = pos.view(rt.n2, rt.dim)
     rows = rt.n2 if with_cls else rt.n1
@@ -266,7 +301,7 @@ class EncoderFn(torch.autograd.Function):
         for P in blocks:
             g1, b1, wqkv, bqkv, wproj, bproj, g2, b2, w1, bb1, w2, bb2 = P
             xa, sa = _attn_branch_fwd(rt, x, g1, b1, wqkv, bqkv, wproj, bproj, batch, n)
-            xb, sm = _mlp_fwd(rt, xa, g2, b2, w1, bb1, w2, bb2)
+            xb, sm = _mlp_fwd(rt, xa, g2, b2, w1, bb1, w2, bb2, grad)
             if grad:
                 tape.append((x, sa, xa, sm))
             x = xb
@@ -303,6 +338,56 @@ class EncoderFn(torch.autograd.Function):
 
 
 # ---------------------------------------------------------------------------------------------
+# pair-cached decoder for similarity-matrix inference (hisfrag.py:213-231; SURVEY.md section 8(f) rank 2)
+# ---------------------------------------------------------------------------------------------
+# hisfrag.py:226-229 calls model(x1[idx1], x2[idx2]) per pair batch, so the reference (and DecoderFn) re-embeds image 2 and
+# re-runs norm_context + the kv projection of every decoder block for EVERY pair.  Neither depends on the pair:
+#   * prepare_x2 (vision_transformer.py:390-395) depends on image j only  -> image2_tokens(), once per image;
+#   * cross-attention keys / values (:177-179) depend on image i's features only -> context_kv(), once per image-1 row block;
+# the pair batch then gathers token rows by index j and the attention kernel reads K / V by index i (vited_attention_fwd_indexed).
+@torch.no_grad()
+def image2_tokens(rt: Runtime, img, pw, pb, pos, cls):
+    """[n, N2, D] fp32: patch embedding + cls row + pos_embed of every image (timm _pos_embed), the decoder's input stream."""
+    x, _, batch, _ = _patch_tokens_fwd(rt, img, pw, pb, pos, with_cls=True, cls=cls)
+    return x.view(batch, rt.n2, rt.dim)
+
+
+@torch.no_grad()
+def context_kv(rt: Runtime, feats, blocks):
+    """Per decoder block: kv = Linear_kv(norm_context(features)) as [b1, N1, 2 D] in the activation dtype (columns [2][h][hd])."""
+    b1 = feats.shape[0]
+    ctxf = feats.detach().contiguous().float().view(b1 * rt.n1, rt.dim)
+    out = []
+    for P in blocks:
+        gx, bx, wkv, bkv = P[8], P[9], P[12], P[13]
+        hc, _, _ = ops.layernorm_fwd(ctxf, gx, bx, LN_EPS, rt.act_dtype)
+        out.append(ops.gemm(hc, rt.weight(wkv), bias=bkv).view(b1, rt.n1, 2 * rt.dim))
+    return out
+
+
+@torch.no_grad()
+def decoder_cached(rt: Runtime, tokens2, j_idx, kvs, i_idx, params):
+    """Logits [P, C] of the pairs (image-1 row i_idx[p] of the cached block, image j_idx[p]): forward_second_part + forward_head
+    (vision_transformer.py:397-405,417) on cached image-2 tokens and cached cross-attention keys / values."""
+    gN, bN, wh, bh = params[4:8]
+    ns, nb = 8, len(DEC_BLOCK_KEYS)
+    d, n = rt.dim, rt.n2
+    batch = j_idx.numel()
+    x = tokens2.index_select(0, j_idx).view(batch * n, d)
+    for l in range(rt.c_depth):
+        g1, b1, wqkv, bqkv, wproj, bproj, gc, bc, gx, bx, wq, bq, wkv, bkv, wcp, bcp, g2, b2, w1, bb1, w2, bb2 = params[ns + l * nb: ns + (l + 1) * nb]
+        xa, _ = _attn_branch_fwd(rt, x, g1, b1, wqkv, bqkv, wproj, bproj, batch, n)
+        hq, _, _ = ops.layernorm_fwd(xa, gc, bc, LN_EPS, rt.act_dtype)
+        q = ops.gemm(hq, rt.weight(wq), bias=bq)
+        kv3 = kvs[l]
+        oc, _ = ops.attention_fwd(q.view(batch, n, d), kv3[:, :, 0:d], kv3[:, :, d:2 * d], rt.heads, rt.scale, kv_index=i_idx)
+        xb = ops.gemm(oc.view(batch * n, d), rt.weight(wcp), epilogue=EPI_RESIDUAL, bias=bcp, residual=xa)
+        x, _ = _mlp_fwd(rt, xb, g2, b2, w1, bb1, w2, bb2, grad=False)
+    y, _, _ = ops.layernorm_fwd(x.view(batch, n, d)[:, 0, :], gN, bN, LN_EPS, rt.act_dtype)
+    return ops.gemm(y, rt.weight(wh), epilogue=EPI_STORE_F32, bias=bh)
+
+
+# ---------------------------------------------------------------------------------------------
 # decoder + head: forward_second_part + forward_head (vision_transformer.py:390-405,417)
 # ---------------------------------------------------------------------------------------------
 class DecoderFn(torch.autograd.Function):
@@ -330,7 +415,7 @@ class DecoderFn(torch.autograd.Function):
             oc, lse_c = ops.attention_fwd(q.view(batch, n, d), kv3[:, :, 0:d], kv3[:, :, d:2 * d], rt.heads, rt.scale)
             oc = oc.view(batch * n, d)
             xb = ops.gemm(oc, rt.weight(wcp), epilogue=EPI_RESIDUAL, bias=bcp, residual=xa)
-            xc, sm = _mlp_fwd(rt, xb, g2, b2, w1, bb1, w2, bb2)
+            xc, sm = _mlp_fwd(rt, xb, g2, b2, w1, bb1, w2, bb2, grad)
             if grad:
                 tape.append((x, sa, xa, (mq, rq, hq, mc, rc, hc, q, kv, oc, lse_c), xb, sm))
             x = xc

@@ -159,6 +159,8 @@ class VisionTransformerCustom(nn.Module):
         self.keep_attn = False
         self.arch_version = arch_version.lower()
         self.compute_dtype = compute_dtype
+        # uint8 inputs are normalised inside the patch-embedding kernel: ToTensor + Normalize(0.5, 0.5) of data/transforms.py:14-18
+        self.input_mean, self.input_std = (0.5,) * in_chans, (0.5,) * in_chans
         hidden = int(embed_dim * mlp_ratio)
         self.patch_embed = _PatchEmbed(img_size, patch_size, in_chans, embed_dim)
         n1 = self.patch_embed.num_patches
@@ -196,6 +198,7 @@ class VisionTransformerCustom(nn.Module):
                          num_heads=self.num_heads, act_dtype=dt)
             self._runtimes[dt] = rt
         rt.direct_grads = bool(getattr(self, 'direct_param_grads', False))
+        rt.input_mean, rt.input_std = self.input_mean, self.input_std
         return rt
 
     def _encoder_params(self):
@@ -231,6 +234,32 @@ class VisionTransformerCustom(nn.Module):
                 raise NotImplementedError('x2_index (gather-in-kernel) is an inference path: call it under torch.no_grad()')
             x2_index = x2_index.to(device=x2.device, dtype=torch.int64).contiguous()
         return F_.DecoderFn.apply(self.runtime(), x1_feats, x2, x2_index, *self._decoder_params())
+
+    # -- pair-cached inference (engine.pairwise_similarity) ---------------------------------
+    supports_pair_cache = True
+
+    @torch.no_grad()
+    def cache_image2_tokens(self, images):
+        """prepare_x2 (vision_transformer.py:390-395) of every image, once: [n, N2, D] fp32."""
+        self._check_images(images)
+        p = self._decoder_params()
+        return F_.image2_tokens(self.runtime(), images, p[0], p[1], p[2], p[3])
+
+    @torch.no_grad()
+    def cache_context_kv(self, feats):
+        """Cross-attention keys / values of every decoder block for a block of image-1 features (:177-179), once per block."""
+        rt = self.runtime()
+        p = self._decoder_params()
+        nb = len(DEC_BLOCK_KEYS)
+        return F_.context_kv(rt, feats, [p[8 + l * nb: 8 + (l + 1) * nb] for l in range(self.c_depth)])
+
+    @torch.no_grad()
+    def forward_pairs_cached(self, tokens2, j_idx, kvs, i_idx):
+        """== self(feats[i_idx], images[j_idx]) (hisfrag.py:226-229) from the two caches."""
+        dev = tokens2.device
+        j_idx = j_idx.to(device=dev, dtype=torch.int64).contiguous()
+        i_idx = i_idx.to(device=dev, dtype=torch.int64).contiguous()
+        return F_.decoder_cached(self.runtime(), tokens2, j_idx, kvs, i_idx, self._decoder_params())
 
     def forward(self, x, x2=None, forward_first_part=False, x2_index=None):
         if forward_first_part:

@@ -123,10 +123,13 @@ class WeightShadowPlan:
             _lib.check(_lib.load().vited_cast_weights(_ptr(self.table), self.count, self.total_tiles, _stream()), 'vited_cast_weights')
 
 
-def patchify(img: torch.Tensor, patch: int, dtype: torch.dtype, batch_index: torch.Tensor | None = None) -> torch.Tensor:
-    """img fp32 [B, C, S, S] (any batch stride, dense [C, S, S]) -> [B * (S/p)^2, C*p*p]."""
+def patchify(img: torch.Tensor, patch: int, dtype: torch.dtype, batch_index: torch.Tensor | None = None,
+             mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5)) -> torch.Tensor:
+    """img fp32 [B, C, S, S] (any batch stride, dense [C, S, S]) -> [B * (S/p)^2, C*p*p].  uint8 images are normalised on the
+    fly: (pixel / 255 - mean[c]) / std[c] (``vited_patchify_u8``)."""
     _need_gpu(img, batch_index)
-    if img.dtype != torch.float32:
+    u8 = img.dtype == torch.uint8
+    if not u8 and img.dtype != torch.float32:
         img = img.float()
     assert img.dim() == 4 and img.shape[2] == img.shape[3], 'expected [B, C, S, S]'
     b, c, s, _ = img.shape
@@ -138,6 +141,13 @@ def patchify(img: torch.Tensor, patch: int, dtype: torch.dtype, batch_index: tor
         nb = batch_index.numel()
     g = s // patch
     out = torch.empty((nb * g * g, c * patch * patch), dtype=dtype, device=img.device)
+    if u8:
+        import ctypes
+        m = (ctypes.c_float * c)(*[float(v) for v in list(mean)[:c]])
+        sd = (ctypes.c_float * c)(*[float(v) for v in list(std)[:c]])
+        _lib.check(_lib.load().vited_patchify_u8(_ptr(img), img.stride(0), _ptr(batch_index), _ptr(out), _code(dtype), nb, c, s, patch,
+                                                 ctypes.cast(m, ctypes.c_void_p), ctypes.cast(sd, ctypes.c_void_p), _stream()), 'vited_patchify_u8')
+        return out
     _lib.check(_lib.load().vited_patchify(_ptr(img), img.stride(0), _ptr(batch_index), _ptr(out), _code(dtype), nb, c, s,
                                           patch, _stream()), 'vited_patchify')
     return out
@@ -338,22 +348,27 @@ def _head_view(t: torch.Tensor, heads: int, head_dim: int):
     return t.stride(0), t.stride(1)
 
 
-def attention_fwd(q, k, v, heads: int, scale: float):
+def attention_fwd(q, k, v, heads: int, scale: float, kv_index=None):
     """q [B,Nq,D], k/v [B,Nk,D] (strided views of the packed qkv / kv projections are fine)
-    -> (o [B,Nq,D] contiguous, lse fp32 [B,H,Nq])."""
-    _need_gpu(q, k, v)
+    -> (o [B,Nq,D] contiguous, lse fp32 [B,H,Nq]).  With ``kv_index`` (int64 [B]) batch item b attends over
+    k[kv_index[b]] / v[kv_index[b]] and k / v may hold any number of items (inference only)."""
+    _need_gpu(q, k, v, kv_index)
     b, nq, d = q.shape
     nk = k.shape[1]
     hd = d // heads
-    assert q.dtype == k.dtype == v.dtype and k.shape == v.shape and k.shape[0] == b and k.shape[2] == d
+    assert q.dtype == k.dtype == v.dtype and k.shape == v.shape and k.shape[2] == d
+    if kv_index is None:
+        assert k.shape[0] == b
+    else:
+        assert kv_index.dtype == torch.int64 and kv_index.is_contiguous() and kv_index.numel() == b
     q_bs, q_ts = _head_view(q, heads, hd)
     k_bs, k_ts = _head_view(k, heads, hd)
     v_bs, v_ts = _head_view(v, heads, hd)
     o = torch.empty((b, nq, d), dtype=q.dtype, device=q.device)
     lse = torch.empty((b, heads, nq), dtype=torch.float32, device=q.device)
-    _lib.check(_lib.load().vited_attention_fwd(_ptr(q), q_bs, q_ts, _ptr(k), k_bs, k_ts, _ptr(v), v_bs, v_ts, _ptr(o),
-                                               nq * d, d, _ptr(lse), _code(q.dtype), b, heads, nq, nk, hd, float(scale),
-                                               _stream()), 'vited_attention_fwd')
+    _lib.check(_lib.load().vited_attention_fwd_indexed(_ptr(q), q_bs, q_ts, _ptr(k), k_bs, k_ts, _ptr(v), v_bs, v_ts, _ptr(kv_index),
+                                                       _ptr(o), nq * d, d, _ptr(lse), _code(q.dtype), b, heads, nq, nk, hd,
+                                                       float(scale), _stream()), 'vited_attention_fwd')
     return o, lse
 
 
