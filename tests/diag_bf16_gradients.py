@@ -72,6 +72,13 @@ def rel(a, b):
     return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
 
 
+def like(tap, ref, batch):
+    """The last decoder block of the HIP path runs on the cls rows only (functions._dec_block_fwd): compare those rows."""
+    if tap.numel() == ref.numel():
+        return ref.reshape(-1)
+    return ref.reshape(batch, -1, ref.shape[-1])[:, 0, :].reshape(-1)
+
+
 def anatomy(case, dev):
     import vited_amd as V
     s, batch = CASES[case]
@@ -102,14 +109,14 @@ def anatomy(case, dev):
         n_blk = s.depth if kind == 'enc' else s.c_depth
         for i in range(n_blk):
             fx, fd = f'{kind}.x.{i}', f'{kind}.dx.{i}'
-            ref_x, ref_d = t32[fx].reshape(-1), t32[fd].reshape(-1)
-            rows.append((f'{kind}{i}', rel(th[fx].reshape(-1), ref_x), rel(tac[fx].reshape(-1), ref_x),
-                         rel(th[fd].reshape(-1), ref_d), rel(tac[fd].reshape(-1), ref_d)))
+            ref_x, ref_d = like(th[fx], t32[fx], batch), like(th[fd], t32[fd], batch)
+            rows.append((f'{kind}{i}', rel(th[fx].reshape(-1), ref_x), rel(like(th[fx], tac[fx], batch), ref_x),
+                         rel(th[fd].reshape(-1), ref_d), rel(like(th[fd], tac[fd], batch), ref_d)))
     cross_rows = []
     for i in range(s.c_depth):
         cross_rows.append((i,) + tuple(v for k in ('q', 'kv', 'oc', 'doc', 'dq', 'dkv')
-                                       for v in (rel(th[f'dec.{k}.{i}'].reshape(-1), t32[f'dec.{k}.{i}'].reshape(-1)),
-                                                 rel(tac[f'dec.{k}.{i}'].reshape(-1), t32[f'dec.{k}.{i}'].reshape(-1)))))
+                                       for v in (rel(th[f'dec.{k}.{i}'].reshape(-1), like(th[f'dec.{k}.{i}'], t32[f'dec.{k}.{i}'], batch)),
+                                                 rel(like(th[f'dec.{k}.{i}'], tac[f'dec.{k}.{i}'], batch), like(th[f'dec.{k}.{i}'], t32[f'dec.{k}.{i}'], batch)))))
     tot = lambda g: (sum(float((g[n].double() - g32[n].double()).norm() ** 2) for n in g32) / sum(float(g32[n].double().norm() ** 2) for n in g32)) ** 0.5
     return {'rows': rows, 'cross': cross_rows, 'logits': (rel(lh.detach().cpu(), l32), rel(lac, l32)), 'grads': (tot(gh), tot(gac)),
             'per_param': {n: (rel(gh[n], g32[n]), rel(gac[n], g32[n]), float(g32[n].norm())) for n in g32}}

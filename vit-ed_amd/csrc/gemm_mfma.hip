@@ -60,7 +60,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 // ---- NT stage: A tile [128 rows][BKT bf16] then B tile, each wave DMAs 32 rows of both ---------------
-template <int BKT, int WM>
+template <int BKT, int WM, bool ASM_DMA = false>
 __device__ __forceinline__ void nt_stage_load(const bf16* __restrict__ A, int64_t lda, const bf16* __restrict__ B,
                                               int64_t ldb, int64_t m0, int64_t n0, int64_t M, int64_t N, int64_t k0,
                                               char* stage, int wave, int lane) {
@@ -72,7 +72,8 @@ __device__ __forceinline__ void nt_stage_load(const bf16* __restrict__ A, int64_
         const int c = cp ^ C::swz(r);
         int64_t gm = m0 + r;
         gm = gm < M ? gm : M - 1;
-        glds16(A + gm * lda + k0 + c * 8, stage + (wave * 32 + i * C::ROWS_PER_DMA) * C::ROW_BYTES);
+        if constexpr (ASM_DMA) glds16_asm(A + gm * lda + k0 + c * 8, stage + (wave * 32 + i * C::ROWS_PER_DMA) * C::ROW_BYTES);
+        else glds16(A + gm * lda + k0 + c * 8, stage + (wave * 32 + i * C::ROWS_PER_DMA) * C::ROW_BYTES);
     }
     constexpr int RB = BN / (2 * WM);                         // B: 128 rows over all waves
 #pragma unroll
@@ -81,11 +82,14 @@ __device__ __forceinline__ void nt_stage_load(const bf16* __restrict__ A, int64_
         const int c = cp ^ C::swz(r);
         int64_t gn = n0 + r;
         gn = gn < N ? gn : N - 1;
-        glds16(B + gn * ldb + k0 + c * 8, stage + C::A_BYTES + (wave * RB + i * C::ROWS_PER_DMA) * C::ROW_BYTES);
+        if constexpr (ASM_DMA) glds16_asm(B + gn * ldb + k0 + c * 8, stage + C::A_BYTES + (wave * RB + i * C::ROWS_PER_DMA) * C::ROW_BYTES);
+        else glds16(B + gn * ldb + k0 + c * 8, stage + C::A_BYTES + (wave * RB + i * C::ROWS_PER_DMA) * C::ROW_BYTES);
     }
 }
 
-template <int EPI, int BKT, int WM>
+// STAGES = 2: two LDS stages, the next stage's DMA in flight under the current stage's MFMAs (builtin LDS-DMA, __syncthreads).
+// STAGES >= 3: a ring with STAGES - 1 stages in flight across the barrier (inline-asm LDS-DMA, counted vmcnt, raw s_barrier).
+template <int EPI, int BKT, int WM, int STAGES = 2>
 __global__ void __launch_bounds__(128 * WM)
 gemm_nt_mfma_kernel(const bf16* __restrict__ A, int64_t lda, const bf16* __restrict__ B, int64_t ldb, int64_t M, int64_t N,
                     int64_t K, int tiles_n, int ntiles, EpiParams ep) {
@@ -103,18 +107,36 @@ gemm_nt_mfma_kernel(const bf16* __restrict__ A, int64_t lda, const bf16* __restr
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     using C = NtCfg<BKT, WM>;
+    constexpr bool RING = STAGES >= 3;
+    constexpr int PER = 32 / C::ROWS_PER_DMA + (BN / (2 * WM)) / C::ROWS_PER_DMA;   // DMA instructions per stage per wave
     const int nk = (int)(K / BKT);
-    nt_stage_load<BKT, WM>(A, lda, B, ldb, m0, n0, M, N, 0, smem, wave, lane);
+    nt_stage_load<BKT, WM, RING>(A, lda, B, ldb, m0, n0, M, N, 0, smem, wave, lane);
+    if constexpr (RING) {
+#pragma unroll
+        for (int pre = 1; pre < STAGES - 1; ++pre)
+            if (pre < nk) nt_stage_load<BKT, WM, RING>(A, lda, B, ldb, m0, n0, M, N, (int64_t)pre * BKT, smem + pre * C::STAGE_BYTES, wave, lane);
+    }
     const int fr = lane & 15, fq = lane >> 4;
     const int64_t mtile = m0 + wr * 64, ntile = n0 + wc * 64;
     EpiPrefetch<EPI> pf;   // epilogue operands are fetched after the K loop, one 16-row sub-tile ahead: held across the
                            // loop their 64 VGPRs cost a workgroup per CU (measured: -11 % proj+res, -7 % dz, -17 % fc2+res)
     for (int t = 0; t < nk; ++t) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();  // stage t landed for every wave; everyone is done reading stage t-1
-        if (t + 1 < nk)
-            nt_stage_load<BKT, WM>(A, lda, B, ldb, m0, n0, M, N, (int64_t)(t + 1) * BKT, smem + ((t + 1) & 1) * C::STAGE_BYTES, wave, lane);
-        const char* sa = smem + (t & 1) * C::STAGE_BYTES;
+        if constexpr (RING) {
+            const int ahead = nk - 1 - t;                    // stages issued after stage t
+            if (ahead >= STAGES - 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((STAGES - 2) * PER) : "memory");
+            else if (ahead == 2 && STAGES > 4) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * PER) : "memory");
+            else if (ahead == 1 && STAGES > 3) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PER) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();   // stage t landed for every wave; everyone is done reading stage t-1
+            asm volatile("" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();  // stage t landed for every wave; everyone is done reading stage t-1
+        }
+        if (t + STAGES - 1 < nk)
+            nt_stage_load<BKT, WM, RING>(A, lda, B, ldb, m0, n0, M, N, (int64_t)(t + STAGES - 1) * BKT,
+                                         smem + ((t + STAGES - 1) % STAGES) * C::STAGE_BYTES, wave, lane);
+        const char* sa = smem + (t % STAGES) * C::STAGE_BYTES;
         const char* sb = sa + C::A_BYTES;
         // All operand fragments of the stage are requested first, then the MFMAs run behind counted lgkmcnt waits:
         // left to itself the compiler keeps ~6 fragments live and waits lgkmcnt(0) four times per K-step, exposing the
@@ -182,14 +204,22 @@ bool gemm_nt_mfma_supported(const void* A, int64_t lda, const void* B, int64_t l
     return true;
 }
 
-template <int EPI, int BKT, int WM>
+template <int EPI, int BKT, int WM, int STAGES = 2>
 static void launch_nt(const bf16* a, int64_t lda, const bf16* b, int64_t ldb, int64_t M, int64_t N, int64_t K, const EpiParams& ep,
                       hipStream_t s) {
     using C = NtCfg<BKT, WM>;
     const int tiles_n = (int)ceil_div64(N, BN);
     const int ntiles = (int)ceil_div64(M, C::BM) * tiles_n;
-    auto kernel = gemm_nt_mfma_kernel<EPI, BKT, WM>;
-    hipLaunchKernelGGL(kernel, dim3(ntiles), dim3(128 * WM), 2 * C::STAGE_BYTES, s, a, lda, b, ldb, M, N, K, tiles_n, ntiles, ep);
+    auto kernel = gemm_nt_mfma_kernel<EPI, BKT, WM, STAGES>;
+    constexpr int LDS = STAGES * C::STAGE_BYTES;
+    if (LDS > 65536) {
+        static bool done = false;
+        if (!done) {
+            hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+            done = true;
+        }
+    }
+    hipLaunchKernelGGL(kernel, dim3(ntiles), dim3(128 * WM), LDS, s, a, lda, b, ldb, M, N, K, tiles_n, ntiles, ep);
 }
 
 template <int EPI>
@@ -198,12 +228,29 @@ static void dispatch_nt(const bf16* a, int64_t lda, const bf16* b, int64_t ldb, 
     // tuning/diagnostic overrides: VITED_NT_BK = 32 | 64, VITED_NT_WM = 2 | 4
     static const int force_bk = getenv("VITED_NT_BK") ? atoi(getenv("VITED_NT_BK")) : 0;
     static const int force_wm = getenv("VITED_NT_WM") ? atoi(getenv("VITED_NT_WM")) : 0;
+    static const int force_st = getenv("VITED_NT_STAGES") ? atoi(getenv("VITED_NT_STAGES")) : 0;   // 3 / 4: the asm-DMA ring
     // BK = 32 (4 workgroups / CU) pays only when the grid is large: at N = 384 (1,536 tiles) BK = 64 is 9-14 % faster
     const bool shallow = force_bk ? force_bk == 32 : (K <= 512 && N >= 768);
     // measured (scratch/gemm_bench.py, M = 65536): the 256-row tile wins 5-10 % on plain-store K = 384 GEMMs with
     // N >= 768 (qkv, kv, fc1) and loses on the register-heavier epilogues, so it is used only there
     const bool tall = force_wm ? force_wm == 4 : (EPI == VITED_EPI_STORE && shallow && N >= 768 && M >= 8192);
-    if (shallow && tall) launch_nt<EPI, 32, 4>(a, lda, b, ldb, M, N, K, ep, s);
+    if (force_st == 3) {
+        if (shallow && tall) launch_nt<EPI, 32, 4, 3>(a, lda, b, ldb, M, N, K, ep, s);
+        else if (shallow) launch_nt<EPI, 32, 2, 3>(a, lda, b, ldb, M, N, K, ep, s);
+        else if (tall) launch_nt<EPI, 64, 4, 3>(a, lda, b, ldb, M, N, K, ep, s);
+        else launch_nt<EPI, 64, 2, 3>(a, lda, b, ldb, M, N, K, ep, s);
+        return;
+    }
+    if (force_st == 4) {
+        if (shallow && tall) launch_nt<EPI, 32, 4, 4>(a, lda, b, ldb, M, N, K, ep, s);
+        else if (shallow) launch_nt<EPI, 32, 2, 4>(a, lda, b, ldb, M, N, K, ep, s);
+        else if (tall) launch_nt<EPI, 64, 4, 3>(a, lda, b, ldb, M, N, K, ep, s);
+        else launch_nt<EPI, 64, 2, 3>(a, lda, b, ldb, M, N, K, ep, s);
+        return;
+    }
+    // the three-stage asm-DMA ring (72 KB, 2 workgroups per CU, two stages in flight each) pays on the plain-store 256 x 128 tiles
+    // only: qkv 82 -> 78 us, kv 56 -> 54; every other variant loses occupancy to it (BK = 64: 96 KB = one workgroup per CU, +50 %)
+    if (shallow && tall) launch_nt<EPI, 32, 4, 3>(a, lda, b, ldb, M, N, K, ep, s);
     else if (shallow) launch_nt<EPI, 32, 2>(a, lda, b, ldb, M, N, K, ep, s);
     else if (tall) launch_nt<EPI, 64, 4>(a, lda, b, ldb, M, N, K, ep, s);
     else launch_nt<EPI, 64, 2>(a, lda, b, ldb, M, N, K, ep, s);

@@ -128,13 +128,26 @@ __device__ __forceinline__ void epilogue_subtile(const EpiParams& p, const EpiPr
                 bf16x8 pd, pg;     // one exponential serves both: exp(-z^2/2) is the Gaussian density AND the erfc tail
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
+#ifdef NT_DBG_NO_GELU
+                    pd[e] = (bf16)v[e];
+                    pg[e] = (bf16)(v[e] * 0.5f);
+#else
                     float cdf, ex;
                     gelu_parts_fast(v[e], cdf, ex);
                     pd[e] = (bf16)fmaf(v[e] * 0.39894228040143268f, ex, cdf);
                     pg[e] = (bf16)(v[e] * cdf);
+#endif
                 }
+#ifdef NT_DBG_SKIP_STORES
+                asm volatile("" :: "v"(pd), "v"(pg));
+#else
                 *(bf16x8*)((bf16*)p.out + m * p.ldo + n) = pd;
+#ifdef NT_DBG_SKIP_OUT2
+                asm volatile("" :: "v"(pg));
+#else
                 *(bf16x8*)((bf16*)p.out2 + m * p.ldo + n) = pg;
+#endif
+#endif
                 continue;
             }
             bf16x8 pk;

@@ -50,6 +50,7 @@ class Runtime:
         self.act_dtype = act_dtype
         self.direct_grads = False   # accumulate parameter gradients straight into existing p.grad (engine.FlatGradients)
         self.input_mean, self.input_std = (0.5, 0.5, 0.5), (0.5, 0.5, 0.5)   # Normalize() of data/transforms.py:14-18, for uint8 inputs
+        self.cls_tail = os.environ.get('VITED_CLS_TAIL', '1') != '0'   # last decoder block on the cls rows only (exact; see _dec_block_fwd)
         self.fused_mlp = os.environ.get('VITED_FUSED_MLP', '1') != '0'   # vited_mlp_fwd on the no-grad paths
         self.tap = None             # test/diagnostic: a dict that receives clones of per-block activations and gradients
         self.pinned = False         # a captured hipGraph reads the shadow buffers: never free one, only refresh in place
@@ -376,20 +377,121 @@ def decoder_cached(rt: Runtime, tokens2, j_idx, kvs, i_idx, params):
     x = tokens2.index_select(0, j_idx).view(batch * n, d)
     for l in range(rt.c_depth):
         g1, b1, wqkv, bqkv, wproj, bproj, gc, bc, gx, bx, wq, bq, wkv, bkv, wcp, bcp, g2, b2, w1, bb1, w2, bb2 = params[ns + l * nb: ns + (l + 1) * nb]
-        xa, _ = _attn_branch_fwd(rt, x, g1, b1, wqkv, bqkv, wproj, bproj, batch, n)
+        cls_only = rt.cls_tail and l == rt.c_depth - 1          # see _dec_block_fwd: the last block runs on the cls row alone
+        if not cls_only:
+            xa, _ = _attn_branch_fwd(rt, x, g1, b1, wqkv, bqkv, wproj, bproj, batch, n)
+            nq = n
+        else:
+            h1, _, _ = ops.layernorm_fwd(x, g1, b1, LN_EPS, rt.act_dtype)
+            qkv3 = ops.gemm(h1, rt.weight(wqkv), bias=bqkv).view(batch, n, 3 * d)
+            o0, _ = ops.attention_fwd(qkv3[:, 0:1, 0:d], qkv3[:, :, d:2 * d], qkv3[:, :, 2 * d:3 * d], rt.heads, rt.scale)
+            xa = ops.gemm(o0.view(batch, d), rt.weight(wproj), epilogue=EPI_RESIDUAL, bias=bproj, residual=_dense_rows(x.view(batch, n, d)[:, 0, :]))
+            nq = 1
         hq, _, _ = ops.layernorm_fwd(xa, gc, bc, LN_EPS, rt.act_dtype)
         q = ops.gemm(hq, rt.weight(wq), bias=bq)
         kv3 = kvs[l]
-        oc, _ = ops.attention_fwd(q.view(batch, n, d), kv3[:, :, 0:d], kv3[:, :, d:2 * d], rt.heads, rt.scale, kv_index=i_idx)
-        xb = ops.gemm(oc.view(batch * n, d), rt.weight(wcp), epilogue=EPI_RESIDUAL, bias=bcp, residual=xa)
+        oc, _ = ops.attention_fwd(q.view(batch, nq, d), kv3[:, :, 0:d], kv3[:, :, d:2 * d], rt.heads, rt.scale, kv_index=i_idx)
+        xb = ops.gemm(oc.view(batch * nq, d), rt.weight(wcp), epilogue=EPI_RESIDUAL, bias=bcp, residual=xa)
         x, _ = _mlp_fwd(rt, xb, g2, b2, w1, bb1, w2, bb2, grad=False)
-    y, _, _ = ops.layernorm_fwd(x.view(batch, n, d)[:, 0, :], gN, bN, LN_EPS, rt.act_dtype)
+    xcls = x if (rt.cls_tail and rt.c_depth > 0) else x.view(batch, n, d)[:, 0, :]
+    y, _, _ = ops.layernorm_fwd(xcls, gN, bN, LN_EPS, rt.act_dtype)
     return ops.gemm(y, rt.weight(wh), epilogue=EPI_STORE_F32, bias=bh)
 
 
 # ---------------------------------------------------------------------------------------------
 # decoder + head: forward_second_part + forward_head (vision_transformer.py:390-405,417)
 # ---------------------------------------------------------------------------------------------
+def _dense_rows(t):
+    """[rows, D] copy with row stride D (``.contiguous()`` keeps the strides of a one-row view, and the GEMM epilogue needs ldo)."""
+    out = torch.empty(t.shape, dtype=t.dtype, device=t.device)
+    out.copy_(t)
+    return out
+
+
+def _dec_block_fwd(rt, x, ctxf, P, batch, n, grad, cls_only):
+    """One CrossBlock forward (vision_transformer.py:268-272).  ``cls_only`` (the LAST decoder block): only x[:, 0] of the
+    block's output reaches the head (:400, :417 - the final norm and the head are row-wise), and within a CrossBlock the
+    token rows only mix in the self-attention, as keys / values.  So after the block's qkv projection everything runs on the
+    cls row alone: self-attention for query 0, proj, the whole cross-attention query side and the MLP - 1 row instead of
+    N2 = 65 / 1025 per pair - with identical logits and identical gradients (the dropped rows' outputs are dead, their
+    gradients exactly zero).  Returns (block output, tape entry)."""
+    g1, b1, wqkv, bqkv, wproj, bproj, gc, bc, gx, bx, wq, bq, wkv, bkv, wcp, bcp, g2, b2, w1, bb1, w2, bb2 = P
+    d = rt.dim
+    if not cls_only:
+        xa, sa = _attn_branch_fwd(rt, x, g1, b1, wqkv, bqkv, wproj, bproj, batch, n)
+        nq = n
+    else:
+        h1, m1, r1 = ops.layernorm_fwd(x, g1, b1, LN_EPS, rt.act_dtype)
+        qkv = ops.gemm(h1, rt.weight(wqkv), bias=bqkv)            # K and V of every row feed query 0
+        qkv3 = qkv.view(batch, n, 3 * d)
+        o0, lse0 = ops.attention_fwd(qkv3[:, 0:1, 0:d], qkv3[:, :, d:2 * d], qkv3[:, :, 2 * d:3 * d], rt.heads, rt.scale)
+        o0 = o0.view(batch, d)
+        x0 = _dense_rows(x.view(batch, n, d)[:, 0, :])
+        xa = ops.gemm(o0, rt.weight(wproj), epilogue=EPI_RESIDUAL, bias=bproj, residual=x0)
+        sa = (m1, r1, h1, qkv, o0, lse0)
+        nq = 1
+    # cross attention: q from image-2 tokens, k/v from image-1 features (:174-200)
+    hq, mq, rq = ops.layernorm_fwd(xa, gc, bc, LN_EPS, rt.act_dtype)
+    hc, mc, rc = ops.layernorm_fwd(ctxf, gx, bx, LN_EPS, rt.act_dtype)
+    q = ops.gemm(hq, rt.weight(wq), bias=bq)
+    kv = ops.gemm(hc, rt.weight(wkv), bias=bkv)                      # [Mc, 2D], columns [2][h][hd] (:178)
+    kv3 = kv.view(batch, rt.n1, 2 * d)
+    oc, lse_c = ops.attention_fwd(q.view(batch, nq, d), kv3[:, :, 0:d], kv3[:, :, d:2 * d], rt.heads, rt.scale)
+    oc = oc.view(batch * nq, d)
+    xb = ops.gemm(oc, rt.weight(wcp), epilogue=EPI_RESIDUAL, bias=bcp, residual=xa)
+    xc, sm = _mlp_fwd(rt, xb, g2, b2, w1, bb1, w2, bb2, grad)
+    entry = (x, sa, xa, (mq, rq, hq, mc, rc, hc, q, kv, oc, lse_c), xb, sm) if grad else None
+    return xc, entry
+
+
+def _dec_block_bwd(rt, dx, dx_lp, ctxf, dctx, P, entry, batch, n, cls_only, tap_index):
+    """Backward of _dec_block_fwd.  dx / dx_lp: gradient w.r.t. the block's output (all rows, or the cls rows when cls_only).
+    Returns (d input fp32, its low-precision copy, d context (accumulated in place), the 22 parameter gradients)."""
+    g1, b1, wqkv, bqkv, wproj, bproj, gc, bc, gx, bx, wq, bq, wkv, bkv, wcp, bcp, g2, b2, w1, bb1, w2, bb2 = P
+    d = rt.dim
+    x, sa, xa, sc, xb, sm = entry
+    mq, rq, hq, mc, rc, hc, q, kv, oc, lse_c = sc
+    nq = 1 if cls_only else n
+    dx, dx_lp, (dg2, db2, dw1, dbb1, dw2, dbb2) = _mlp_bwd(rt, dx, dx_lp, xb, g2, b2, w1, bb1, w2, bb2, sm)
+    # cross attention
+    doc, dwcp, dbcp = _linear_bwd(rt, dx_lp, oc, wcp, bcp)
+    dq = torch.empty_like(q)
+    dkv = torch.empty_like(kv)
+    kv3, dkv3 = kv.view(batch, rt.n1, 2 * d), dkv.view(batch, rt.n1, 2 * d)
+    ops.attention_bwd(q.view(batch, nq, d), kv3[:, :, 0:d], kv3[:, :, d:2 * d], oc.view(batch, nq, d),
+                      doc.view(batch, nq, d), lse_c, rt.heads, rt.scale, dq.view(batch, nq, d), dkv3[:, :, 0:d],
+                      dkv3[:, :, d:2 * d])
+    if rt.tap is not None:
+        i = tap_index
+        rt.tap[f'dec.doc.{i}'], rt.tap[f'dec.dq.{i}'], rt.tap[f'dec.dkv.{i}'] = doc.clone(), dq.clone(), dkv.clone()
+        rt.tap[f'dec.q.{i}'], rt.tap[f'dec.kv.{i}'], rt.tap[f'dec.oc.{i}'] = q.clone(), kv.clone(), oc.clone()
+    dhq, dwq, dbq = _linear_bwd(rt, dq, hq, wq, bq)
+    dhc, dwkv, dbkv = _linear_bwd(rt, dkv, hc, wkv, bkv)
+    dx, dx_lp, dgc, dbc = _ln_bwd(rt, dhq, xa, gc, bc, mq, rq, dx_in=dx, want_lp=not rt.exact)
+    if rt.exact:
+        dx_lp = dx
+    # d(context) accumulates over the c_depth blocks in fp32, in place
+    dctx, _, dgx, dbx = _ln_bwd(rt, dhc, ctxf, gx, bx, mc, rc, dx_in=dctx, dx_out=dctx)
+    if not cls_only:
+        dx, dx_lp, (dg1, db1, dwqkv, dbqkv, dwp, dbp) = _attn_branch_bwd(rt, dx, dx_lp, x, g1, b1, wqkv, bqkv, wproj, bproj, sa, batch, n)
+    else:
+        m1, r1, h1, qkv, o0, lse0 = sa
+        do0, dwp, dbp = _linear_bwd(rt, dx_lp, o0, wproj, bproj)
+        qkv3 = qkv.view(batch, n, 3 * d)
+        dqkv = torch.zeros_like(qkv)                 # d(q) of the rows that never queried is zero
+        dqkv3 = dqkv.view(batch, n, 3 * d)
+        ops.attention_bwd(qkv3[:, 0:1, 0:d], qkv3[:, :, d:2 * d], qkv3[:, :, 2 * d:3 * d], o0.view(batch, 1, d), do0.view(batch, 1, d),
+                          lse0, rt.heads, rt.scale, dqkv3[:, 0:1, 0:d], dqkv3[:, :, d:2 * d], dqkv3[:, :, 2 * d:3 * d])
+        dh1, dwqkv, dbqkv = _linear_bwd(rt, dqkv, h1, wqkv, bqkv)
+        dres = torch.zeros((batch * n, d), dtype=torch.float32, device=dx.device)   # the residual path carries gradient on the cls rows only
+        dres.view(batch, n, d)[:, 0, :].copy_(dx)
+        dx, dx_lp, dg1, db1 = _ln_bwd(rt, dh1, x, g1, b1, m1, r1, dx_in=dres, want_lp=not rt.exact)
+        if rt.exact:
+            dx_lp = dx
+    return dx, dx_lp, dctx, [dg1, db1, dwqkv, dbqkv, dwp, dbp, dgc, dbc, dgx, dbx, dwq, dbq, dwkv, dbkv, dwcp, dbcp,
+                             dg2, db2, dw1, dbb1, dw2, dbb2]
+
+
 class DecoderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rt: Runtime, feats, img2, img2_index, *params):
@@ -403,31 +505,20 @@ class DecoderFn(torch.autograd.Function):
         ctxf = feats.detach().contiguous().float().view(batch * rt.n1, rt.dim)
         tape = []
         d = rt.dim
-        for P in blocks:
-            g1, b1, wqkv, bqkv, wproj, bproj, gc, bc, gx, bx, wq, bq, wkv, bkv, wcp, bcp, g2, b2, w1, bb1, w2, bb2 = P
-            xa, sa = _attn_branch_fwd(rt, x, g1, b1, wqkv, bqkv, wproj, bproj, batch, n)
-            # cross attention: q from image-2 tokens, k/v from image-1 features (:174-200)
-            hq, mq, rq = ops.layernorm_fwd(xa, gc, bc, LN_EPS, rt.act_dtype)
-            hc, mc, rc = ops.layernorm_fwd(ctxf, gx, bx, LN_EPS, rt.act_dtype)
-            q = ops.gemm(hq, rt.weight(wq), bias=bq)
-            kv = ops.gemm(hc, rt.weight(wkv), bias=bkv)                      # [Mc, 2D], columns [2][h][hd] (:178)
-            kv3 = kv.view(batch, rt.n1, 2 * d)
-            oc, lse_c = ops.attention_fwd(q.view(batch, n, d), kv3[:, :, 0:d], kv3[:, :, d:2 * d], rt.heads, rt.scale)
-            oc = oc.view(batch * n, d)
-            xb = ops.gemm(oc, rt.weight(wcp), epilogue=EPI_RESIDUAL, bias=bcp, residual=xa)
-            xc, sm = _mlp_fwd(rt, xb, g2, b2, w1, bb1, w2, bb2, grad)
+        cls_tail = rt.cls_tail and rt.c_depth > 0
+        for i, P in enumerate(blocks):
+            x, entry = _dec_block_fwd(rt, x, ctxf, P, batch, n, grad, cls_tail and i == rt.c_depth - 1)
             if grad:
-                tape.append((x, sa, xa, (mq, rq, hq, mc, rc, hc, q, kv, oc, lse_c), xb, sm))
-            x = xc
+                tape.append(entry)
             if rt.tap is not None:
-                rt.tap[f'dec.x.{len(tape) - 1 if grad else 0}'] = x.clone()
+                rt.tap[f'dec.x.{i}'] = x.clone()
         # final norm on the cls rows only (LayerNorm is row-wise; only x[:, 0] reaches the head, :400,:417)
-        x3 = x.view(batch, n, d)
-        y, mN, rN = ops.layernorm_fwd(x3[:, 0, :], gN, bN, LN_EPS, rt.act_dtype)
+        xcls = x if cls_tail else x.view(batch, n, d)[:, 0, :]
+        y, mN, rN = ops.layernorm_fwd(xcls, gN, bN, LN_EPS, rt.act_dtype)
         logits = ops.gemm(y, rt.weight(wh), epilogue=EPI_STORE_F32, bias=bh)
         if grad:
             ctx.rt, ctx.tape, ctx.patches, ctx.batch, ctx.params = rt, tape, patches, batch, params
-            ctx.ctxf, ctx.final = ctxf, (x, y, mN, rN)
+            ctx.ctxf, ctx.final, ctx.cls_tail = ctxf, (xcls, y, mN, rN), cls_tail
             ctx.feats_needs_grad = feats.requires_grad
         return logits
 
@@ -438,57 +529,40 @@ class DecoderFn(torch.autograd.Function):
         pw, pb, pos, cls, gN, bN, wh, bh = params[:8]
         ns, nb = 8, len(DEC_BLOCK_KEYS)
         grads = [None] * len(params)
-        x, y, mN, rN = ctx.final
+        xcls, y, mN, rN = ctx.final
         # head: logits = y Wh^T + bh
         dl = _lp(rt, dlogits.contiguous().float())
         wh_act = rt.weight(wh)
         dy = ops.gemm(dl, wh_act, b_layout=B_KN)                         # [B, D]
         dwh, dbh = _weight_grads(rt, dl, y, wh, bh)
-        # final LayerNorm touches the cls rows only; every other row of d(x) is zero
-        dx = torch.zeros((batch * n, d), dtype=torch.float32, device=dy.device)
-        dx3 = dx.view(batch, n, d)
-        dx_lp = None
-        dx_lp3 = None
-        if not rt.exact:
-            dx_lp = torch.zeros((batch * n, d), dtype=rt.act_dtype, device=dy.device)
-            dx_lp3 = dx_lp.view(batch, n, d)[:, 0, :]
-        _, _, dgN, dbN = _ln_bwd(rt, dy, x.view(batch, n, d)[:, 0, :], gN, bN, mN, rN, dx_out=dx3[:, 0, :], dx_lp=dx_lp3)
+        if ctx.cls_tail:
+            # the last block ran on the cls rows only: so does its gradient
+            dx, dx_lp, dgN, dbN = _ln_bwd(rt, dy, xcls, gN, bN, mN, rN, want_lp=not rt.exact)
+        else:
+            # final LayerNorm touches the cls rows only; every other row of d(x) is zero
+            dx = torch.zeros((batch * n, d), dtype=torch.float32, device=dy.device)
+            dx3 = dx.view(batch, n, d)
+            dx_lp = None
+            dx_lp3 = None
+            if not rt.exact:
+                dx_lp = torch.zeros((batch * n, d), dtype=rt.act_dtype, device=dy.device)
+                dx_lp3 = dx_lp.view(batch, n, d)[:, 0, :]
+            _, _, dgN, dbN = _ln_bwd(rt, dy, xcls, gN, bN, mN, rN, dx_out=dx3[:, 0, :], dx_lp=dx_lp3)
         if rt.exact:
             dx_lp = dx
         grads[4], grads[5], grads[6], grads[7] = dgN, dbN, dwh, dbh
         dctx = None
         for i in reversed(range(rt.c_depth)):
-            (g1, b1, wqkv, bqkv, wproj, bproj, gc, bc, gx, bx, wq, bq, wkv, bkv, wcp, bcp, g2, b2, w1, bb1, w2,
-             bb2) = params[ns + i * nb: ns + (i + 1) * nb]
-            x, sa, xa, sc, xb, sm = ctx.tape[i]
+            P = params[ns + i * nb: ns + (i + 1) * nb]
+            entry = ctx.tape[i]
             ctx.tape[i] = None
-            mq, rq, hq, mc, rc, hc, q, kv, oc, lse_c = sc
-            dx, dx_lp, (dg2, db2, dw1, dbb1, dw2, dbb2) = _mlp_bwd(rt, dx, dx_lp, xb, g2, b2, w1, bb1, w2, bb2, sm)
-            # cross attention
-            doc, dwcp, dbcp = _linear_bwd(rt, dx_lp, oc, wcp, bcp)
-            dq = torch.empty_like(q)
-            dkv = torch.empty_like(kv)
-            kv3, dkv3 = kv.view(batch, rt.n1, 2 * d), dkv.view(batch, rt.n1, 2 * d)
-            ops.attention_bwd(q.view(batch, n, d), kv3[:, :, 0:d], kv3[:, :, d:2 * d], oc.view(batch, n, d),
-                              doc.view(batch, n, d), lse_c, rt.heads, rt.scale, dq.view(batch, n, d), dkv3[:, :, 0:d],
-                              dkv3[:, :, d:2 * d])
-            if rt.tap is not None:
-                rt.tap[f'dec.doc.{i}'], rt.tap[f'dec.dq.{i}'], rt.tap[f'dec.dkv.{i}'] = doc.clone(), dq.clone(), dkv.clone()
-                rt.tap[f'dec.q.{i}'], rt.tap[f'dec.kv.{i}'], rt.tap[f'dec.oc.{i}'] = q.clone(), kv.clone(), oc.clone()
-            dhq, dwq, dbq = _linear_bwd(rt, dq, hq, wq, bq)
-            dhc, dwkv, dbkv = _linear_bwd(rt, dkv, hc, wkv, bkv)
-            dx, dx_lp, dgc, dbc = _ln_bwd(rt, dhq, xa, gc, bc, mq, rq, dx_in=dx, want_lp=not rt.exact)
-            if rt.exact:
-                dx_lp = dx
-            # d(context) accumulates over the c_depth blocks in fp32, in place
-            dctx, _, dgx, dbx = _ln_bwd(rt, dhc, ctx.ctxf, gx, bx, mc, rc, dx_in=dctx, dx_out=dctx)
-            dx, dx_lp, (dg1, db1, dwqkv, dbqkv, dwp, dbp) = _attn_branch_bwd(rt, dx, dx_lp, x, g1, b1, wqkv, bqkv, wproj, bproj, sa, batch, n)
+            dx, dx_lp, dctx, blk = _dec_block_bwd(rt, dx, dx_lp, ctx.ctxf, dctx, P, entry, batch, n,
+                                                  ctx.cls_tail and i == rt.c_depth - 1, i)
             if rt.tap is not None:
                 rt.tap[f'dec.dx.{i}'] = dx.clone()      # gradient w.r.t. the INPUT of decoder block i
                 rt.tap[f'dec.dctx.{i}'] = dctx.clone()  # running d(features) after blocks c_depth-1 .. i
             base = ns + i * nb
-            grads[base: base + nb] = [dg1, db1, dwqkv, dbqkv, dwp, dbp, dgc, dbc, dgx, dbx, dwq, dbq, dwkv, dbkv, dwcp, dbcp,
-                                      dg2, db2, dw1, dbb1, dw2, dbb2]
+            grads[base: base + nb] = blk
         dpw, dpb, dpos, dcls = _patch_tokens_bwd(rt, dx, ctx.patches, pw, pb, pos, with_cls=True, batch=batch)
         grads[0], grads[1], grads[2], grads[3] = dpw, dpb, dpos, dcls.view_as(cls)
         dfeats = dctx.view(batch, rt.n1, d) if ctx.feats_needs_grad and dctx is not None else None
