@@ -1,10 +1,10 @@
 #!/bin/bash
 # Collects the round's profile evidence on the GPU box (run through gpurun from the repo root):
-#   gpurun --timeout 1200 -- 'bash profiles/collect.sh r01'
+#   gpurun --timeout 1200 -- 'bash profiles/collect.sh r02'
 # Writes raw output under gpurun_out/prof_<tag>/ ; profiles/summarize.py turns it into the committed CSVs.
 # Separate passes: kernel trace + stats, then one --pmc pass per counter (FETCH_SIZE and WRITE_SIZE do not fit one pass).
 set -e
-TAG=${1:-r01}
+TAG=${1:-r02}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$OLDPWD"

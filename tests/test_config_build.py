@@ -77,8 +77,10 @@ def test_product_has_no_cpu_fallback(vited):
         m(torch.zeros(2, 2, 3, 64, 64))
     with pytest.raises(AssertionError):
         m.to('cpu')(torch.zeros(2, 3, 3, 64, 64))
+    m = vited.VisionTransformerCustom(img_size=64, patch_size=8, embed_dim=384, depth=1, c_depth=1, keep_attn=True)   # visualisation slow path: accepted
+    assert m.keep_attn and m.blocks[0].attn.keep_attn and m.cross_blocks[0].cross_attn.keep_attn
     with pytest.raises(NotImplementedError):
-        vited.VisionTransformerCustom(img_size=64, patch_size=8, embed_dim=384, keep_attn=True)
+        vited.VisionTransformerCustom(img_size=64, patch_size=8, embed_dim=1280, num_heads=16)   # beyond the LayerNorm kernels: says so at build time
     with pytest.raises(NotImplementedError):
         cfg = vited.config_from_yaml(CFG_T, ['MODEL.TYPE', 'vit'])
         vited.build_model(cfg)

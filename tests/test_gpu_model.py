@@ -424,3 +424,58 @@ def test_uint8_inputs_and_prefetcher(vited, gpu):
     x = batches[0][0][:, 0].to(gpu)
     ref = vited.ops.patchify(torch.addcmul(torch.full((5, 3, 64, 64), -1.0, device=gpu), x.float(), torch.full((1,), 1.0 / 127.5, device=gpu)), 8, torch.float32)
     torch.testing.assert_close(vited.ops.patchify(x, 8, torch.float32), ref, rtol=0, atol=2e-7)
+
+
+def test_keep_attn_slow_path_matches_the_oracle(vited, gpu):
+    """MODEL.PJS.KEEP_ATTN (vision_transformer.py:67-75,188-195; read by scripts/visualise_attentions.py:218-244): the fused
+    kernels still produce the logits, and get_attn() / get_attn_gradients() return the materialised softmax(q k^T / sqrt(hd))
+    and d loss / d attn of encoder self-attention, decoder self-attention and decoder cross-attention."""
+    s = vo.ViTEDShape(depth=1, c_depth=1)
+    torch.manual_seed(6)
+    oracle = vo.OracleViTED(s)
+    model = vited.VisionTransformerCustom(img_size=s.img_size, patch_size=s.patch_size, num_classes=s.num_classes, embed_dim=s.embed_dim,
+                                          depth=1, c_depth=1, num_heads=s.num_heads, keep_attn=True).to(gpu)
+    model.compute_dtype = torch.float32
+    model.load_state_dict(oracle.state_dict())
+    with pytest.raises(RuntimeError, match='no attention map'):
+        model.blocks[0].attn.get_attn()
+    x = torch.randn(3, 2, 3, 64, 64).clamp(-1, 1)
+    y = (torch.rand(3, 4) > 0.5).float()
+    out = model(x.to(gpu))
+    torch.nn.functional.binary_cross_entropy_with_logits(out, y.to(gpu)).backward()
+    # the oracle, opened up at the three attentions
+    maps = {}
+
+    def attn_of(q, k, key):
+        a = torch.softmax((vo._heads(q, s.num_heads) * s.head_dim ** -0.5) @ vo._heads(k, s.num_heads).transpose(-2, -1), dim=-1)
+        a.retain_grad()
+        maps[key] = a
+        return a
+
+    def sdpa(a, v):
+        o = a @ vo._heads(v, s.num_heads)
+        return o.transpose(1, 2).reshape(o.shape[0], o.shape[2], -1)
+
+    lin = torch.nn.functional.linear
+    x1, x2 = torch.unbind(x, 1)
+    t = oracle._patch_tokens(x1) + oracle.pos_embed[:, 1:]
+    blk = oracle.blocks[0]
+    q, k, v = lin(vo._ln(blk.norm1, t), blk.attn.qkv.weight, blk.attn.qkv.bias).chunk(3, -1)
+    t = t + lin(sdpa(attn_of(q, k, 'enc'), v), blk.attn.proj.weight, blk.attn.proj.bias)
+    feats = t + vo._mlp(blk.mlp, vo._ln(blk.norm2, t))
+    u = oracle.prepare_x2(x2)
+    blk = oracle.cross_blocks[0]
+    q, k, v = lin(vo._ln(blk.norm1, u), blk.attn.qkv.weight, blk.attn.qkv.bias).chunk(3, -1)
+    u = u + lin(sdpa(attn_of(q, k, 'dec'), v), blk.attn.proj.weight, blk.attn.proj.bias)
+    ca = blk.cross_attn
+    q = lin(vo._ln(blk.norm_cross, u), ca.q.weight, ca.q.bias)
+    k, v = lin(vo._ln(blk.norm_context, feats), ca.kv.weight, ca.kv.bias).chunk(2, -1)
+    u = u + lin(sdpa(attn_of(q, k, 'cross'), v), ca.proj.weight, ca.proj.bias)
+    u = u + vo._mlp(blk.mlp, vo._ln(blk.norm2, u))
+    lo = oracle.forward_head(vo._ln(oracle.norm, u))
+    torch.nn.functional.binary_cross_entropy_with_logits(lo, y).backward()
+    torch.testing.assert_close(out.detach().cpu(), lo.detach(), rtol=1e-3, atol=1e-5)
+    for key, mod in (('enc', model.blocks[0].attn), ('dec', model.cross_blocks[0].attn), ('cross', model.cross_blocks[0].cross_attn)):
+        torch.testing.assert_close(mod.get_attn().cpu(), maps[key].detach(), rtol=1e-3, atol=1e-6, msg=lambda m: f'{key} map: {m}')
+        g = maps[key].grad
+        torch.testing.assert_close(mod.get_attn_gradients().cpu(), g, rtol=2e-3, atol=1e-6 * float(g.abs().max()) + 1e-9, msg=lambda m: f'{key} grad: {m}')

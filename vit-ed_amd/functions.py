@@ -50,6 +50,8 @@ class Runtime:
         self.act_dtype = act_dtype
         self.direct_grads = False   # accumulate parameter gradients straight into existing p.grad (engine.FlatGradients)
         self.input_mean, self.input_std = (0.5, 0.5, 0.5), (0.5, 0.5, 0.5)   # Normalize() of data/transforms.py:14-18, for uint8 inputs
+        self.keep_attn = False      # MODEL.PJS.KEEP_ATTN: also materialise the attention maps (visualisation slow path)
+        self.attn_store = {}        # (kind, block index, 'attn' | 'cross_attn') -> {'attn': ..., 'grad': ...}
         self.cls_tail = os.environ.get('VITED_CLS_TAIL', '1') != '0'   # last decoder block on the cls rows only (exact; see _dec_block_fwd)
         self.fused_mlp = os.environ.get('VITED_FUSED_MLP', '1') != '0'   # vited_mlp_fwd on the no-grad paths
         self.tap = None             # test/diagnostic: a dict that receives clones of per-block activations and gradients
@@ -171,17 +173,38 @@ def _linear_bwd(rt, dy, x_saved, w, b=None, want_dx=True, aux=None):
     return dx, dw, db
 
 
-def _self_attn_fwd(rt, h, wqkv, bqkv, batch, n):
+def _keep_attention(rt, key, q, k):
+    """KEEP_ATTN slow path (vision_transformer.py:67-75,188-195; consumer: scripts/visualise_attentions.py): materialise
+    softmax(q k^T * scale) [B, h, Nq, Nk] with plain PyTorch ops, beside the fused kernels that never form it."""
+    b, nq, d = q.shape
+    qh = q.float().reshape(b, nq, rt.heads, rt.head_dim).transpose(1, 2)
+    kh = k.float().reshape(b, k.shape[1], rt.heads, rt.head_dim).transpose(1, 2)
+    rt.attn_store.setdefault(key, {})['attn'] = torch.softmax((qh * rt.scale) @ kh.transpose(-2, -1), dim=-1)
+
+
+def _keep_attention_grad(rt, key, do, v):
+    """What the reference's ``attn.register_hook(self.save_attn_gradients)`` records: d loss / d attn = dO V^T."""
+    b, nq, d = do.shape
+    doh = do.float().reshape(b, nq, rt.heads, rt.head_dim).transpose(1, 2)
+    vh = v.float().reshape(b, v.shape[1], rt.heads, rt.head_dim).transpose(1, 2)
+    rt.attn_store.setdefault(key, {})['grad'] = doh @ vh.transpose(-2, -1)
+
+
+def _self_attn_fwd(rt, h, wqkv, bqkv, batch, n, key=None):
     d = rt.dim
     qkv = ops.gemm(h, rt.weight(wqkv), bias=bqkv)                   # [M, 3D], columns [3][h][hd] (:58)
     qkv3 = qkv.view(batch, n, 3 * d)
     o, lse = ops.attention_fwd(qkv3[:, :, 0:d], qkv3[:, :, d:2 * d], qkv3[:, :, 2 * d:3 * d], rt.heads, rt.scale)
+    if rt.keep_attn and key is not None:
+        _keep_attention(rt, key, qkv3[:, :, 0:d], qkv3[:, :, d:2 * d])
     return qkv, o.view(batch * n, d), lse
 
 
-def _self_attn_bwd(rt, do, qkv, o, lse, batch, n):
+def _self_attn_bwd(rt, do, qkv, o, lse, batch, n, key=None):
     d = rt.dim
     qkv3 = qkv.view(batch, n, 3 * d)
+    if rt.keep_attn and key is not None:
+        _keep_attention_grad(rt, key, do.view(batch, n, d), qkv3[:, :, 2 * d:3 * d])
     dqkv = torch.empty_like(qkv)
     dqkv3 = dqkv.view(batch, n, 3 * d)
     ops.attention_bwd(qkv3[:, :, 0:d], qkv3[:, :, d:2 * d], qkv3[:, :, 2 * d:3 * d], o.view(batch, n, d),
@@ -237,17 +260,17 @@ def _mlp_bwd(rt, dy, dy_lp, x, g, b, w1, b1, w2, b2, saved):
     return dx, (dx if rt.exact else dx_lp), (dg, db, dw1, db1, dw2, db2)
 
 
-def _attn_branch_fwd(rt, x, g, b, wqkv, bqkv, wproj, bproj, batch, n):
+def _attn_branch_fwd(rt, x, g, b, wqkv, bqkv, wproj, bproj, batch, n, key=None):
     h, mean, rstd = ops.layernorm_fwd(x, g, b, LN_EPS, rt.act_dtype)
-    qkv, o, lse = _self_attn_fwd(rt, h, wqkv, bqkv, batch, n)
+    qkv, o, lse = _self_attn_fwd(rt, h, wqkv, bqkv, batch, n, key)
     y = ops.gemm(o, rt.weight(wproj), epilogue=EPI_RESIDUAL, bias=bproj, residual=x)
     return y, (mean, rstd, h, qkv, o, lse)
 
 
-def _attn_branch_bwd(rt, dy, dy_lp, x, g, b, wqkv, bqkv, wproj, bproj, saved, batch, n):
+def _attn_branch_bwd(rt, dy, dy_lp, x, g, b, wqkv, bqkv, wproj, bproj, saved, batch, n, key=None):
     mean, rstd, h, qkv, o, lse = saved
     do, dwp, dbp = _linear_bwd(rt, dy_lp, o, wproj, bproj)
-    dqkv = _self_attn_bwd(rt, do, qkv, o, lse, batch, n)
+    dqkv = _self_attn_bwd(rt, do, qkv, o, lse, batch, n, key)
     dh, dwq, dbq = _linear_bwd(rt, dqkv, h, wqkv, bqkv)
     dx, dx_lp, dg, db = _ln_bwd(rt, dh, x, g, b, mean, rstd, dx_in=dy, want_lp=not rt.exact)
     return dx, (dx if rt.exact else dx_lp), (dg, db, dwq, dbq, dwp, dbp)
@@ -301,7 +324,7 @@ class EncoderFn(torch.autograd.Function):
         tape = []
         for P in blocks:
             g1, b1, wqkv, bqkv, wproj, bproj, g2, b2, w1, bb1, w2, bb2 = P
-            xa, sa = _attn_branch_fwd(rt, x, g1, b1, wqkv, bqkv, wproj, bproj, batch, n)
+            xa, sa = _attn_branch_fwd(rt, x, g1, b1, wqkv, bqkv, wproj, bproj, batch, n, key=('blocks', len(tape), 'attn'))
             xb, sm = _mlp_fwd(rt, xa, g2, b2, w1, bb1, w2, bb2, grad)
             if grad:
                 tape.append((x, sa, xa, sm))
@@ -326,7 +349,8 @@ class EncoderFn(torch.autograd.Function):
             x, sa, xa, sm = ctx.tape[i]
             ctx.tape[i] = None
             dx, dx_lp, (dg2, db2, dw1, dbb1, dw2, dbb2) = _mlp_bwd(rt, dx, dx_lp, xa, g2, b2, w1, bb1, w2, bb2, sm)
-            dx, dx_lp, (dg1, db1, dwq, dbq, dwp, dbp) = _attn_branch_bwd(rt, dx, dx_lp, x, g1, b1, wqkv, bqkv, wproj, bproj, sa, batch, n)
+            dx, dx_lp, (dg1, db1, dwq, dbq, dwp, dbp) = _attn_branch_bwd(rt, dx, dx_lp, x, g1, b1, wqkv, bqkv, wproj, bproj, sa, batch, n,
+                                                                         key=('blocks', i, 'attn'))
             if rt.tap is not None:
                 rt.tap[f'enc.dx.{i}'] = dx.clone()      # gradient w.r.t. the INPUT of encoder block i
             base = 3 + i * nb
@@ -408,7 +432,7 @@ def _dense_rows(t):
     return out
 
 
-def _dec_block_fwd(rt, x, ctxf, P, batch, n, grad, cls_only):
+def _dec_block_fwd(rt, x, ctxf, P, batch, n, grad, cls_only, index=0):
     """One CrossBlock forward (vision_transformer.py:268-272).  ``cls_only`` (the LAST decoder block): only x[:, 0] of the
     block's output reaches the head (:400, :417 - the final norm and the head are row-wise), and within a CrossBlock the
     token rows only mix in the self-attention, as keys / values.  So after the block's qkv projection everything runs on the
@@ -418,7 +442,7 @@ def _dec_block_fwd(rt, x, ctxf, P, batch, n, grad, cls_only):
     g1, b1, wqkv, bqkv, wproj, bproj, gc, bc, gx, bx, wq, bq, wkv, bkv, wcp, bcp, g2, b2, w1, bb1, w2, bb2 = P
     d = rt.dim
     if not cls_only:
-        xa, sa = _attn_branch_fwd(rt, x, g1, b1, wqkv, bqkv, wproj, bproj, batch, n)
+        xa, sa = _attn_branch_fwd(rt, x, g1, b1, wqkv, bqkv, wproj, bproj, batch, n, key=('cross_blocks', index, 'attn'))
         nq = n
     else:
         h1, m1, r1 = ops.layernorm_fwd(x, g1, b1, LN_EPS, rt.act_dtype)
@@ -437,6 +461,8 @@ def _dec_block_fwd(rt, x, ctxf, P, batch, n, grad, cls_only):
     kv = ops.gemm(hc, rt.weight(wkv), bias=bkv)                      # [Mc, 2D], columns [2][h][hd] (:178)
     kv3 = kv.view(batch, rt.n1, 2 * d)
     oc, lse_c = ops.attention_fwd(q.view(batch, nq, d), kv3[:, :, 0:d], kv3[:, :, d:2 * d], rt.heads, rt.scale)
+    if rt.keep_attn:
+        _keep_attention(rt, ('cross_blocks', index, 'cross_attn'), q.view(batch, nq, d), kv3[:, :, 0:d])
     oc = oc.view(batch * nq, d)
     xb = ops.gemm(oc, rt.weight(wcp), epilogue=EPI_RESIDUAL, bias=bcp, residual=xa)
     xc, sm = _mlp_fwd(rt, xb, g2, b2, w1, bb1, w2, bb2, grad)
@@ -458,6 +484,8 @@ def _dec_block_bwd(rt, dx, dx_lp, ctxf, dctx, P, entry, batch, n, cls_only, tap_
     dq = torch.empty_like(q)
     dkv = torch.empty_like(kv)
     kv3, dkv3 = kv.view(batch, rt.n1, 2 * d), dkv.view(batch, rt.n1, 2 * d)
+    if rt.keep_attn:
+        _keep_attention_grad(rt, ('cross_blocks', tap_index, 'cross_attn'), doc.view(batch, nq, d), kv3[:, :, d:2 * d])
     ops.attention_bwd(q.view(batch, nq, d), kv3[:, :, 0:d], kv3[:, :, d:2 * d], oc.view(batch, nq, d),
                       doc.view(batch, nq, d), lse_c, rt.heads, rt.scale, dq.view(batch, nq, d), dkv3[:, :, 0:d],
                       dkv3[:, :, d:2 * d])
@@ -473,7 +501,8 @@ def _dec_block_bwd(rt, dx, dx_lp, ctxf, dctx, P, entry, batch, n, cls_only, tap_
     # d(context) accumulates over the c_depth blocks in fp32, in place
     dctx, _, dgx, dbx = _ln_bwd(rt, dhc, ctxf, gx, bx, mc, rc, dx_in=dctx, dx_out=dctx)
     if not cls_only:
-        dx, dx_lp, (dg1, db1, dwqkv, dbqkv, dwp, dbp) = _attn_branch_bwd(rt, dx, dx_lp, x, g1, b1, wqkv, bqkv, wproj, bproj, sa, batch, n)
+        dx, dx_lp, (dg1, db1, dwqkv, dbqkv, dwp, dbp) = _attn_branch_bwd(rt, dx, dx_lp, x, g1, b1, wqkv, bqkv, wproj, bproj, sa, batch, n,
+                                                                           key=('cross_blocks', tap_index, 'attn'))
     else:
         m1, r1, h1, qkv, o0, lse0 = sa
         do0, dwp, dbp = _linear_bwd(rt, dx_lp, o0, wproj, bproj)
@@ -505,9 +534,9 @@ class DecoderFn(torch.autograd.Function):
         ctxf = feats.detach().contiguous().float().view(batch * rt.n1, rt.dim)
         tape = []
         d = rt.dim
-        cls_tail = rt.cls_tail and rt.c_depth > 0
+        cls_tail = rt.cls_tail and rt.c_depth > 0 and not rt.keep_attn    # the visualisation path wants every query row's map
         for i, P in enumerate(blocks):
-            x, entry = _dec_block_fwd(rt, x, ctxf, P, batch, n, grad, cls_tail and i == rt.c_depth - 1)
+            x, entry = _dec_block_fwd(rt, x, ctxf, P, batch, n, grad, cls_tail and i == rt.c_depth - 1, index=i)
             if grad:
                 tape.append(entry)
             if rt.tap is not None:

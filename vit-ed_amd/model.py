@@ -66,11 +66,22 @@ class _SelfAttn(_Holder):
         self.proj = _Linear(d, d)
         self.keep_attn = False
 
-    def get_attn(self):
-        raise NotImplementedError('keep_attn (attention visualisation, scripts/visualise_attentions.py) is outside the '
-                                  'HIP hot path: the fused kernels never materialise the attention matrix')
+    _store, _key = None, None     # set by VisionTransformerCustom: the runtime's attention store and this module's key
 
-    get_attn_gradients = get_attn
+    def _lookup(self, what):
+        ent = (self._store() or {}).get(self._key) if self._store is not None else None
+        if ent is None or what not in ent:
+            raise RuntimeError('no attention map recorded: build the model with MODEL.PJS.KEEP_ATTN True (keep_attn=True) and '
+                               'run a forward' + (' and a backward' if what == 'grad' else '') + ' first')
+        return ent[what]
+
+    def get_attn(self):
+        """softmax(q k^T / sqrt(hd)) [B, h, Nq, Nk] of the last forward (vision_transformer.py:46-47,166-167)."""
+        return self._lookup('attn')
+
+    def get_attn_gradients(self):
+        """d loss / d attn of the last backward (vision_transformer.py:49-50,169-170)."""
+        return self._lookup('grad')
 
 
 class _CrossAttn(_SelfAttn):
@@ -138,9 +149,6 @@ class VisionTransformerCustom(nn.Module):
         live = {k: v for k, v in unsupported.items() if v not in (None, False, 0, 0., '', 'token')}
         if live:
             raise NotImplementedError(f'options outside the shipped pjs configs are not on the HIP hot path: {sorted(live)}')
-        if keep_attn:
-            raise NotImplementedError('KEEP_ATTN=True is the visualisation slow path (vision_transformer.py:67-75); the HIP '
-                                      'hot path never materialises attention')
         if embed_dim % num_heads:
             raise AssertionError('dim should be divisible by num_heads')
         if img_size % patch_size:
@@ -156,7 +164,7 @@ class VisionTransformerCustom(nn.Module):
         self.num_classes, self.embed_dim = num_classes, embed_dim
         self.num_features = embed_dim
         self.depth, self.c_depth, self.num_heads = depth, c_depth, num_heads
-        self.keep_attn = False
+        self.keep_attn = bool(keep_attn)    # visualisation slow path: attention maps are ALSO materialised (PyTorch ops)
         self.arch_version = arch_version.lower()
         self.compute_dtype = compute_dtype
         # uint8 inputs are normalised inside the patch-embedding kernel: ToTensor + Normalize(0.5, 0.5) of data/transforms.py:14-18
@@ -172,6 +180,15 @@ class VisionTransformerCustom(nn.Module):
         self._init_like_timm()  # runs before the decoder exists, exactly as in the reference ctor (:344-347)
         self.cross_blocks = nn.ModuleList([CrossBlock(embed_dim, num_heads, hidden, qkv_bias) for _ in range(c_depth)])
         self._runtimes = {}
+        import weakref
+        me = weakref.ref(self)
+        self._attn_store = {}
+        store = lambda: (me()._attn_store if me() is not None else None)
+        for i, blk in enumerate(self.blocks):
+            blk.attn._store, blk.attn._key, blk.attn.keep_attn = store, ('blocks', i, 'attn'), self.keep_attn
+        for i, blk in enumerate(self.cross_blocks):
+            blk.attn._store, blk.attn._key, blk.attn.keep_attn = store, ('cross_blocks', i, 'attn'), self.keep_attn
+            blk.cross_attn._store, blk.cross_attn._key, blk.cross_attn.keep_attn = store, ('cross_blocks', i, 'cross_attn'), self.keep_attn
         print(f'Using {arch_version} Arch!')
 
     def _init_like_timm(self):
@@ -199,6 +216,7 @@ class VisionTransformerCustom(nn.Module):
             self._runtimes[dt] = rt
         rt.direct_grads = bool(getattr(self, 'direct_param_grads', False))
         rt.input_mean, rt.input_std = self.input_mean, self.input_std
+        rt.keep_attn, rt.attn_store = self.keep_attn, self._attn_store
         return rt
 
     def _encoder_params(self):
