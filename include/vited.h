@@ -168,6 +168,18 @@ int vited_mlp_fwd(const float* x, int64_t ldx, const float* gamma, const float* 
                   const void* w2, const float* b2, float* y, int64_t ldy, void* h, void* gd, void* u, float* mean,
                   float* rstd, int64_t rows, int64_t dim, int64_t hidden, float eps, void* stream);
 
+/* One encoder Block forward (Block.forward, vision_transformer.py:124-127) behind one call: the launch sequence
+ * LayerNorm -> qkv GEMM -> attention -> proj + residual -> fused MLP branch on `stream` (5 launches; 7 when the MLP shape is
+ * outside vited_mlp_fwd's cover).  bf16 activations, fp32 residual stream, inference form (nothing saved for backward).
+ *   x, y       fp32 [batch * tokens, dim] dense; y may not alias x
+ *   wqkv [3 dim, dim], wproj [dim, dim], w1 [hidden, dim], w2 [dim, hidden]   bf16 dense; biases and LayerNorm parameters fp32
+ *   workspace  >= vited_block_workspace_bytes(), 256-byte aligned */
+int64_t vited_block_workspace_bytes(int64_t batch, int64_t tokens, int64_t dim, int64_t hidden, int heads);
+int vited_block_fwd(const float* x, float* y, int64_t batch, int64_t tokens, int64_t dim, int heads, int64_t hidden,
+                    const float* ln1_g, const float* ln1_b, const void* wqkv, const float* bqkv, const void* wproj,
+                    const float* bproj, const float* ln2_g, const float* ln2_b, const void* w1, const float* b1,
+                    const void* w2, const float* b2, float eps, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ---- optimizer step on the flat gradient buffer ----------------- */
 
 /* Gradient clip + AdamW + bf16 weight-shadow refresh + gradient zeroing in two launches; replaces

@@ -405,3 +405,29 @@ def test_mlp_fused_rejects_other_shapes(vited, gpu):
     with pytest.raises(RuntimeError, match='unsupported'):
         ops.mlp_fwd(x, torch.ones(256, device=gpu), torch.zeros(256, device=gpu), _rand((1024, 256), gpu, 2).bfloat16(), torch.zeros(1024, device=gpu),
                     _rand((256, 1024), gpu, 3).bfloat16(), torch.zeros(256, device=gpu), 1e-6)
+
+
+@pytest.mark.parametrize('batch,tokens,heads', [(256, 64, 12), (5, 65, 12), (3, 256, 6)])
+def test_block_fwd_matches_the_oracle_block(vited, gpu, batch, tokens, heads):
+    """vited_block_fwd (Block.forward, vision_transformer.py:124-127, as one C-ABI call) against the CPU oracle's
+    ``encoder_block`` on the same fp32 parameters: bf16 tolerance (3e-2), and identical to the op-by-op HIP sequence."""
+    from oracle import vited_oracle as vo
+    torch.manual_seed(batch + tokens)
+    s = vo.ViTEDShape(num_heads=heads)
+    blk = vo._encoder_bag(s)
+    for p in blk.parameters():
+        if p.dim() > 1:
+            torch.nn.init.trunc_normal_(p, std=.04)
+        else:
+            torch.nn.init.normal_(p, std=.05)
+    blk.norm1.weight.data.add_(1.0)
+    blk.norm2.weight.data.add_(1.0)
+    x = torch.randn(batch, tokens, 384)
+    with torch.no_grad():
+        want = vo.encoder_block(blk, x, heads)
+    g = lambda t: t.detach().to(gpu)
+    bf = lambda t: t.detach().to(gpu).to(torch.bfloat16).contiguous()
+    y = vited.ops.block_fwd(g(x), heads, g(blk.norm1.weight), g(blk.norm1.bias), bf(blk.attn.qkv.weight), g(blk.attn.qkv.bias),
+                            bf(blk.attn.proj.weight), g(blk.attn.proj.bias), g(blk.norm2.weight), g(blk.norm2.bias), bf(blk.mlp.fc1.weight),
+                            g(blk.mlp.fc1.bias), bf(blk.mlp.fc2.weight), g(blk.mlp.fc2.bias))
+    torch.testing.assert_close(y.cpu(), want, rtol=3e-2, atol=3e-2)

@@ -341,6 +341,23 @@ def mlp_fwd(x, gamma, beta, w1, b1, w2, b2, eps: float, save: bool = True, out=N
     return y, ((mean, rstd, h, gd, u) if save else None)
 
 
+def block_fwd(x, heads: int, ln1_g, ln1_b, wqkv, bqkv, wproj, bproj, ln2_g, ln2_b, w1, b1, w2, b2, eps: float = 1e-6):
+    """Encoder Block forward through ``vited_block_fwd``: x fp32 [B, N, D] -> y fp32 [B, N, D] (bf16 weights, inference form)."""
+    _need_gpu(x, wqkv, wproj, w1, w2)
+    assert x.dtype == torch.float32 and x.dim() == 3 and x.is_contiguous()
+    assert all(t.dtype == torch.bfloat16 and t.is_contiguous() for t in (wqkv, wproj, w1, w2))
+    b, n, d = x.shape
+    hidden = w1.shape[0]
+    lib = _lib.load()
+    y = torch.empty_like(x)
+    ws = workspace(lib.vited_block_workspace_bytes(b, n, d, hidden, heads) + 256, x.device)
+    base = (ws.data_ptr() + 255) // 256 * 256
+    _lib.check(lib.vited_block_fwd(_ptr(x), _ptr(y), b, n, d, heads, hidden, _ptr(ln1_g), _ptr(ln1_b), _ptr(wqkv), _ptr(bqkv), _ptr(wproj),
+                                   _ptr(bproj), _ptr(ln2_g), _ptr(ln2_b), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), float(eps), base,
+                                   ws.numel() * 4 - (base - ws.data_ptr()), _stream()), 'vited_block_fwd')
+    return y
+
+
 # ---------------------------------------------------------------------------------------------
 def _head_view(t: torch.Tensor, heads: int, head_dim: int):
     """t is [B, N, heads*head_dim] (a last-dim slice of the packed projection): (ptr-holder, bs, ts)."""
