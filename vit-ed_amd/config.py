@@ -5,7 +5,7 @@ and defaults, YAML files with ``BASE`` parents, the argparse overrides ``main.py
 pass, ``--opts KEY VALUE ...`` last, ``OUTPUT = <output>/<MODEL.NAME>/<TAG>``, and a frozen
 attribute-style node (``config.MODEL.PJS.EMBED_DIM``) with ``defrost() / freeze() / clone() /
 dump() / merge_from_file() / merge_from_list()``.  The shipped YAMLs under ``configs/`` parse to
-the same values as with the reference's loader (tests/test_config.py).
+the same values as with the reference's loader (tests/test_config_build.py).
 """
 from __future__ import annotations
 

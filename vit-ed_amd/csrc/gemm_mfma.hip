@@ -87,6 +87,14 @@ __device__ __forceinline__ void nt_stage_load(const bf16* __restrict__ A, int64_
     }
 }
 
+#ifdef NT_TIMELINE
+// diagnostic build only (make VARIANT=tl EXTRA=-DNT_TIMELINE): per-workgroup time stamps of the NT kernel
+__device__ unsigned long long nt_timeline[16384 * 4];
+extern "C" int vited_debug_timeline(void* dst, int64_t bytes) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(nt_timeline), bytes, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 3;
+}
+#endif
+
 // STAGES = 2: two LDS stages, the next stage's DMA in flight under the current stage's MFMAs (builtin LDS-DMA, __syncthreads).
 // STAGES >= 3: a ring with STAGES - 1 stages in flight across the barrier (inline-asm LDS-DMA, counted vmcnt, raw s_barrier).
 template <int EPI, int BKT, int WM, int STAGES = 2>
@@ -100,6 +108,19 @@ gemm_nt_mfma_kernel(const bf16* __restrict__ A, int64_t lda, const bf16* __restr
     const int tile = xcd_remap(blockIdx.x, ntiles);
     const int64_t m0 = (int64_t)(tile / tiles_n) * (64 * WM), n0 = (int64_t)(tile % tiles_n) * BN;
 
+#ifdef NT_STAGGER_US
+    // Workgroups b, b + 256, b + 512, ... share a CU (8 XCDs x 32 CUs are dealt round-robin).  Started together and doing identical
+    // work they stay in lockstep: the whole chip stages operands (L2 -> LDS bound), then the whole chip stores (HBM bound), and the two
+    // phases ADD (timeline: profiles/nt_timeline.py).  Delaying the k-th resident workgroup of a CU by k slices of the tile time
+    // de-phases them once; identical tile times keep them de-phased.
+    if (blockIdx.x < 256 * NT_STAGGER_SLOTS) {
+        const int slot = blockIdx.x >> 8;
+        for (int i = 0; i < slot * NT_STAGGER_US; ++i) __builtin_amdgcn_s_sleep(32);   // ~1 us per iteration
+    }
+#endif
+#ifdef NT_TIMELINE
+    const unsigned long long tl0 = __builtin_amdgcn_s_memrealtime();
+#endif
     f32x4 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -124,6 +145,8 @@ gemm_nt_mfma_kernel(const bf16* __restrict__ A, int64_t lda, const bf16* __restr
         if constexpr (RING) {
             const int ahead = nk - 1 - t;                    // stages issued after stage t
             if (ahead >= STAGES - 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((STAGES - 2) * PER) : "memory");
+            else if (ahead == 4 && STAGES > 6) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(4 * PER) : "memory");
+            else if (ahead == 3 && STAGES > 5) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(3 * PER) : "memory");
             else if (ahead == 2 && STAGES > 4) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * PER) : "memory");
             else if (ahead == 1 && STAGES > 3) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PER) : "memory");
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -172,6 +195,9 @@ gemm_nt_mfma_kernel(const bf16* __restrict__ A, int64_t lda, const bf16* __restr
         for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
     return;
 #endif
+#ifdef NT_TIMELINE
+    const unsigned long long tl1 = __builtin_amdgcn_s_memrealtime();
+#endif
     // ---- epilogue: accumulators -> per-wave LDS scratch -> full-line row segments (gemm_nt_epilogue.h)
     epilogue_prefetch_bias<EPI>(ep, pf, ntile, N, lane);
     epilogue_prefetch_subtile<EPI>(ep, pf, 0, mtile, ntile, M, N, lane);
@@ -189,6 +215,17 @@ gemm_nt_mfma_kernel(const bf16* __restrict__ A, int64_t lda, const bf16* __restr
         epilogue_subtile<EPI>(ep, pf, sc, i, mtile, ntile, M, N, lane);
         asm volatile("" ::: "memory");
     }
+#ifdef NT_TIMELINE
+    if (threadIdx.x == 0 && blockIdx.x < 16384) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long tl2 = __builtin_amdgcn_s_memrealtime();
+        const unsigned hw = __builtin_amdgcn_s_getreg(63492), xcc = __builtin_amdgcn_s_getreg(6164);
+        nt_timeline[blockIdx.x * 4 + 0] = tl0;
+        nt_timeline[blockIdx.x * 4 + 1] = tl1;
+        nt_timeline[blockIdx.x * 4 + 2] = tl2;
+        nt_timeline[blockIdx.x * 4 + 3] = ((unsigned long long)xcc << 32) | hw;
+    }
+#endif
 }
 
 bool gemm_nt_mfma_supported(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K,
@@ -239,6 +276,11 @@ static void dispatch_nt(const bf16* a, int64_t lda, const bf16* b, int64_t ldb, 
         else if (shallow) launch_nt<EPI, 32, 2, 3>(a, lda, b, ldb, M, N, K, ep, s);
         else if (tall) launch_nt<EPI, 64, 4, 3>(a, lda, b, ldb, M, N, K, ep, s);
         else launch_nt<EPI, 64, 2, 3>(a, lda, b, ldb, M, N, K, ep, s);
+        return;
+    }
+    if (force_st == 5 || force_st == 6) {   // experiments: deep ring of 24 KB stages, one 8-wave workgroup per CU
+        if (force_st == 5) launch_nt<EPI, 32, 4, 5>(a, lda, b, ldb, M, N, K, ep, s);
+        else launch_nt<EPI, 32, 4, 6>(a, lda, b, ldb, M, N, K, ep, s);
         return;
     }
     if (force_st == 4) {
