@@ -599,11 +599,13 @@ def pairwise_similarity(model, images, *, rank: int = 0, world: int = 1, block: 
     scores = []
     was_training = model.training
     model.eval()
-    tokens2 = None
+    tokens2 = q0 = None
     if cached:
         with dtype_ctx:
             lo = r0                                                        # this rank only ever needs images j >= its first row
-            tokens2 = torch.cat([model.cache_image2_tokens(images[c:min(c + 256, n)]) for c in range(lo, n, 256)])
+            parts = [model.cache_image2_tokens(images[c:min(c + 256, n)]) for c in range(lo, n, 256)]
+            tokens2 = torch.cat([t for t, _ in parts])
+            q0 = torch.cat([q for _, q in parts]) if parts[0][1] is not None else None
     for a0 in range(r0, r1, block):
         a1 = min(a0 + block, r1)
         with dtype_ctx:
@@ -614,7 +616,7 @@ def pairwise_similarity(model, images, *, rank: int = 0, world: int = 1, block: 
             i_sub, j_sub = ii[c0:c0 + pair_batch], (jj[c0:c0 + pair_batch] + a0)
             with dtype_ctx:
                 if cached:
-                    out = model.forward_pairs_cached(tokens2, j_sub - r0, kvs, i_sub)
+                    out = model.forward_pairs_cached(tokens2, j_sub - r0, kvs, i_sub, q0)
                 elif by_index:
                     out = model(feats[i_sub], images, x2_index=j_sub)
                 else:

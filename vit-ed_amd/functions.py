@@ -371,10 +371,21 @@ class EncoderFn(torch.autograd.Function):
 #   * cross-attention keys / values (:177-179) depend on image i's features only -> context_kv(), once per image-1 row block;
 # the pair batch then gathers token rows by index j and the attention kernel reads K / V by index i (vited_attention_fwd_indexed).
 @torch.no_grad()
-def image2_tokens(rt: Runtime, img, pw, pb, pos, cls):
-    """[n, N2, D] fp32: patch embedding + cls row + pos_embed of every image (timm _pos_embed), the decoder's input stream."""
+def image2_tokens(rt: Runtime, img, pw, pb, pos, cls, block0=None):
+    """Everything of the decoder that depends on image 2 ALONE, once per image:
+      * x  = patch embedding + cls row + pos_embed (timm _pos_embed), the decoder's input stream;
+      * x' = x + attn(norm1(x)) of the FIRST CrossBlock (its self-attention sees image 2 only: the features enter at the
+             cross-attention that follows, vision_transformer.py:269-270) - unless that block is also the last one (cls-only);
+      * q  = Linear_q(norm_cross(x')) of that block's cross-attention (:176), activation dtype.
+    Returns (x' or x as [n, N2, D] fp32, q [n, N2, D] or None)."""
     x, _, batch, _ = _patch_tokens_fwd(rt, img, pw, pb, pos, with_cls=True, cls=cls)
-    return x.view(batch, rt.n2, rt.dim)
+    if block0 is None or (rt.cls_tail and rt.c_depth == 1):
+        return x.view(batch, rt.n2, rt.dim), None
+    g1, b1, wqkv, bqkv, wproj, bproj, gc, bc, gx, bx, wq, bq = block0[:12]
+    xa, _ = _attn_branch_fwd(rt, x, g1, b1, wqkv, bqkv, wproj, bproj, batch, rt.n2)
+    hq, _, _ = ops.layernorm_fwd(xa, gc, bc, LN_EPS, rt.act_dtype)
+    q = ops.gemm(hq, rt.weight(wq), bias=bq)
+    return xa.view(batch, rt.n2, rt.dim), q.view(batch, rt.n2, rt.dim)
 
 
 @torch.no_grad()
@@ -391,9 +402,10 @@ def context_kv(rt: Runtime, feats, blocks):
 
 
 @torch.no_grad()
-def decoder_cached(rt: Runtime, tokens2, j_idx, kvs, i_idx, params):
+def decoder_cached(rt: Runtime, tokens2, j_idx, kvs, i_idx, params, q0=None):
     """Logits [P, C] of the pairs (image-1 row i_idx[p] of the cached block, image j_idx[p]): forward_second_part + forward_head
-    (vision_transformer.py:397-405,417) on cached image-2 tokens and cached cross-attention keys / values."""
+    (vision_transformer.py:397-405,417) on cached image-2 tokens and cached cross-attention keys / values.  With ``q0`` the cache
+    already holds block 0's self-attention branch and cross-attention queries (image2_tokens with block0)."""
     gN, bN, wh, bh = params[4:8]
     ns, nb = 8, len(DEC_BLOCK_KEYS)
     d, n = rt.dim, rt.n2
@@ -402,7 +414,9 @@ def decoder_cached(rt: Runtime, tokens2, j_idx, kvs, i_idx, params):
     for l in range(rt.c_depth):
         g1, b1, wqkv, bqkv, wproj, bproj, gc, bc, gx, bx, wq, bq, wkv, bkv, wcp, bcp, g2, b2, w1, bb1, w2, bb2 = params[ns + l * nb: ns + (l + 1) * nb]
         cls_only = rt.cls_tail and l == rt.c_depth - 1          # see _dec_block_fwd: the last block runs on the cls row alone
-        if not cls_only:
+        if l == 0 and q0 is not None:
+            xa, nq = x, n                                         # cached: x IS x + attn(norm1(x)) of block 0
+        elif not cls_only:
             xa, _ = _attn_branch_fwd(rt, x, g1, b1, wqkv, bqkv, wproj, bproj, batch, n)
             nq = n
         else:
@@ -411,8 +425,11 @@ def decoder_cached(rt: Runtime, tokens2, j_idx, kvs, i_idx, params):
             o0, _ = ops.attention_fwd(qkv3[:, 0:1, 0:d], qkv3[:, :, d:2 * d], qkv3[:, :, 2 * d:3 * d], rt.heads, rt.scale)
             xa = ops.gemm(o0.view(batch, d), rt.weight(wproj), epilogue=EPI_RESIDUAL, bias=bproj, residual=_dense_rows(x.view(batch, n, d)[:, 0, :]))
             nq = 1
-        hq, _, _ = ops.layernorm_fwd(xa, gc, bc, LN_EPS, rt.act_dtype)
-        q = ops.gemm(hq, rt.weight(wq), bias=bq)
+        if l == 0 and q0 is not None:
+            q = q0.index_select(0, j_idx)
+        else:
+            hq, _, _ = ops.layernorm_fwd(xa, gc, bc, LN_EPS, rt.act_dtype)
+            q = ops.gemm(hq, rt.weight(wq), bias=bq)
         kv3 = kvs[l]
         oc, _ = ops.attention_fwd(q.view(batch, nq, d), kv3[:, :, 0:d], kv3[:, :, d:2 * d], rt.heads, rt.scale, kv_index=i_idx)
         xb = ops.gemm(oc.view(batch * nq, d), rt.weight(wcp), epilogue=EPI_RESIDUAL, bias=bcp, residual=xa)

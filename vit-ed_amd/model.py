@@ -258,10 +258,13 @@ class VisionTransformerCustom(nn.Module):
 
     @torch.no_grad()
     def cache_image2_tokens(self, images):
-        """prepare_x2 (vision_transformer.py:390-395) of every image, once: [n, N2, D] fp32."""
+        """Everything of the decoder that depends on image 2 alone, once per image: prepare_x2 (vision_transformer.py:390-395),
+        the first CrossBlock's self-attention branch and its cross-attention queries.  Returns (tokens [n, N2, D] fp32, q0 | None)."""
         self._check_images(images)
         p = self._decoder_params()
-        return F_.image2_tokens(self.runtime(), images, p[0], p[1], p[2], p[3])
+        nb = len(DEC_BLOCK_KEYS)
+        block0 = p[8: 8 + nb] if self.c_depth else None
+        return F_.image2_tokens(self.runtime(), images, p[0], p[1], p[2], p[3], block0)
 
     @torch.no_grad()
     def cache_context_kv(self, feats):
@@ -272,12 +275,12 @@ class VisionTransformerCustom(nn.Module):
         return F_.context_kv(rt, feats, [p[8 + l * nb: 8 + (l + 1) * nb] for l in range(self.c_depth)])
 
     @torch.no_grad()
-    def forward_pairs_cached(self, tokens2, j_idx, kvs, i_idx):
-        """== self(feats[i_idx], images[j_idx]) (hisfrag.py:226-229) from the two caches."""
+    def forward_pairs_cached(self, tokens2, j_idx, kvs, i_idx, q0=None):
+        """== self(feats[i_idx], images[j_idx]) (hisfrag.py:226-229) from the caches."""
         dev = tokens2.device
         j_idx = j_idx.to(device=dev, dtype=torch.int64).contiguous()
         i_idx = i_idx.to(device=dev, dtype=torch.int64).contiguous()
-        return F_.decoder_cached(self.runtime(), tokens2, j_idx, kvs, i_idx, self._decoder_params())
+        return F_.decoder_cached(self.runtime(), tokens2, j_idx, kvs, i_idx, self._decoder_params(), q0)
 
     def forward(self, x, x2=None, forward_first_part=False, x2_index=None):
         if forward_first_part:
