@@ -284,7 +284,9 @@ def test_gemm_patch_embed_row_remap(vited, gpu, dtype):
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('M,N,K', [(4096, 384, 384), (1000, 1152, 384), (777, 384, 1536), (640, 384, 192), (65, 4, 384),
-                                   (130, 32, 32), (50, 768, 384)])
+                                   (130, 32, 32), (50, 768, 384),
+                                   # the wide (128 x 384) tile: ragged last m-stage, ragged n-tile, several k-panels
+                                   (4099, 1152, 384), (5000, 200, 768), (4128, 384, 1536), (8192, 8, 384)])
 def test_linear_bwd_weight(vited, gpu, dtype, M, N, K):
     ops = vited.ops
     dy = _rand((M, N), gpu, 1, dtype=dtype)
@@ -297,6 +299,19 @@ def test_linear_bwd_weight(vited, gpu, dtype, M, N, K):
     torch.testing.assert_close(db.double(), dy.double().sum(0), rtol=1e-4, atol=1e-4 * math.sqrt(M))
     dw2, db2 = ops.linear_bwd_weight(dy, x)
     assert torch.equal(dw, dw2) and torch.equal(db, db2)  # deterministic (slabs, no atomics)
+
+
+def test_linear_bwd_weight_wide_strided_operands(vited, gpu):
+    """dW of the wide tile from column views of wider buffers (the fused qkv gradient / hidden activations are read in place)."""
+    ops = vited.ops
+    M = 4500
+    dyb = _rand((M, 1152 + 64), gpu, 1, dtype=torch.bfloat16)
+    xb = _rand((M, 768 + 32), gpu, 2, dtype=torch.bfloat16)
+    dy, x = dyb[:, 64:], xb[:, 32:]
+    dw, db = ops.linear_bwd_weight(dy, x)
+    assert ops.last_paths()[0] == 2
+    torch.testing.assert_close(dw.double(), dy.double().t() @ x.double(), rtol=1e-4, atol=1e-4 * math.sqrt(M))
+    torch.testing.assert_close(db.double(), dy.double().sum(0), rtol=1e-4, atol=1e-4 * math.sqrt(M))
 
 
 def _sdpa_ref(q, k, v, heads, scale):

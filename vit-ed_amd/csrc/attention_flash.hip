@@ -63,6 +63,14 @@ __device__ __forceinline__ void lds_row_frags(const char* lds, int t, int fr, in
     for (int c = 0; c < HD / 32; ++c) f[c] = *(const bf16x8*)(lds + SmallCfg<HD>::off(16 * t + fr, 16 * (g + 4 * c)));
 }
 
+// The file is compiled twice (Makefile): FLASH_PART 1 = forward, built with -mllvm -amdgpu-mfma-vgpr-form
+// (the O accumulators stay in VGPRs: no AGPR<->VGPR moves around the rescale, forward +9.6 % at config H);
+// FLASH_PART 2 = backward, built without it (the flag costs the backward kernels ~2 %).  0 = everything.
+#ifndef FLASH_PART
+#define FLASH_PART 0
+#endif
+
+#if FLASH_PART != 2
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
@@ -198,6 +206,9 @@ attn_fwd_flash_kernel(AttnArgs a) {
     }
 }
 
+#endif  // forward
+
+#if FLASH_PART != 1
 // ------------------------------------------------------------------------------------------------
 // backward 1/2: dQ (and delta)
 // ------------------------------------------------------------------------------------------------
@@ -449,9 +460,12 @@ attn_bwd_dkv_flash_kernel(AttnArgs a) {
     }
 }
 
+#endif  // backward
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
+#if FLASH_PART != 2
 template <int HD>
 static int launch_flash_fwd(const AttnArgs& a, hipStream_t s) {
     dim3 grid((unsigned)((a.nq + 64 * FL_W - 1) / (64 * FL_W)), (unsigned)a.heads, (unsigned)a.batch);
@@ -459,6 +473,9 @@ static int launch_flash_fwd(const AttnArgs& a, hipStream_t s) {
     return vited_check_launch();
 }
 
+#endif
+
+#if FLASH_PART != 1
 template <int HD>
 static int launch_flash_bwd(const AttnArgs& a, hipStream_t s) {
     dim3 gq((unsigned)((a.nq + 64 * FL_W - 1) / (64 * FL_W)), (unsigned)a.heads, (unsigned)a.batch);
@@ -468,14 +485,21 @@ static int launch_flash_bwd(const AttnArgs& a, hipStream_t s) {
     return vited_check_launch();
 }
 
+#endif
+
+#if FLASH_PART != 2
 int attention_fwd_flash(const AttnArgs& a, hipStream_t s) {
     if (a.head_dim == 32) return launch_flash_fwd<32>(a, s);
     if (a.head_dim == 64) return launch_flash_fwd<64>(a, s);
     return VITED_ERR_UNSUPPORTED;
 }
 
+#endif
+
+#if FLASH_PART != 1
 int attention_bwd_flash(const AttnArgs& a, hipStream_t s) {
     if (a.head_dim == 32) return launch_flash_bwd<32>(a, s);
     if (a.head_dim == 64) return launch_flash_bwd<64>(a, s);
     return VITED_ERR_UNSUPPORTED;
 }
+#endif

@@ -518,6 +518,226 @@ gemm_tn_mfma_kernel(const bf16* __restrict__ dY, int64_t lddy, const bf16* __res
     }
 }
 
+// ================================================================================================
+// Wide TN: 128 n x 384 k output tile, 512 threads = 8 waves as 2 (n) x 4 (k), each wave 64 n x 96 k = 4 x 6 accumulators.
+// Why: the 128 x 128 kernel above stages 512 B of operands per m-row per 16,384 MACs and every dY / X column panel is
+// re-read by 3 / 12 other tiles (HBM fetch measured at 2.8 x the algorithmic bytes on dW fc1); this tile stages 1,024 B
+// per 49,152 MACs (1.5 x fewer bytes through the ~70 GB/s-per-CU L2 -> LDS path that bounds these kernels), reads dY
+// exactly once, issues 10 transposed fragment reads per 24 MFMAs instead of 8 per 16 ... and X's 768-byte rows are
+// shared by the n-tiles of one m-split on ONE XCD.  One workgroup per CU: a 4-slot ring of 32-row stages
+// (stage = [32 m][128 n] of dY + 3 panels [32 m][128 k] of X = 32 KB, same swizzled 256-byte-row image as above),
+// three stages (96 KB) in flight per CU across the barrier - counted vmcnt, raw s_barrier, LDS-DMA from inline asm.
+// Taken when K is a multiple of 384 (every dW of the embed-384 models: qkv / kv / proj / fc1 / fc2).
+// ================================================================================================
+#define TW_STAGES 4
+#define TW_PANEL_BYTES (32 * 256)
+#define TW_STAGE_BYTES (4 * TW_PANEL_BYTES)
+#define TW_PER 4   // LDS-DMA instructions per stage per wave
+
+// This wave's four 1-KiB pieces of one stage: rows rbase + 4 i + (lane >> 4) of its panel.  src[i] is the lane's source pointer of
+// piece i for the stage (advanced by the caller, 32 rows per stage); the ragged last stage re-derives it with the row clamped.
+__device__ __forceinline__ void tw_stage_issue(const bf16* const (&src)[4], char* stage, int panel, int rbase) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16_asm(src[i], stage + panel * TW_PANEL_BYTES + (rbase + i * 4) * 256);
+}
+
+struct TwFrags {
+    bf16x8 a[4], b[6];
+};
+
+__device__ __forceinline__ void tw_read_frags(TwFrags& f, const char* st, const int (&ya_lo)[4], const int (&ya_hi)[4],
+                                              const int (&xb_lo)[6], const int (&xb_hi)[6]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const bf16x4 lo = tr_read(st + ya_lo[i]);
+        const bf16x4 hi = tr_read(st + ya_hi[i]);
+        f.a[i] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const bf16x4 lo = tr_read(st + xb_lo[j]);
+        const bf16x4 hi = tr_read(st + xb_hi[j]);
+        f.b[j] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+}
+
+template <bool BIAS>
+__global__ void __launch_bounds__(512)
+gemm_tn_wide_kernel(const bf16* __restrict__ dY, int64_t lddy, const bf16* __restrict__ X, int64_t ldx, int64_t M, int64_t N,
+                    int64_t K, int64_t rows_per_split, int tiles_k, float* __restrict__ out, float* __restrict__ bias_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int ntile = gridDim.x;
+    const int lin = xcd_remap(blockIdx.x + blockIdx.y * ntile, ntile * gridDim.y);   // one m-split's tiles share an XCD
+    const int split = lin / ntile, tile_id = lin - split * ntile;
+    const int64_t n0 = (int64_t)(tile_id / tiles_k) * 128, kc0 = (int64_t)(tile_id % tiles_k) * 384;
+    const int64_t mb = (int64_t)split * rows_per_split;
+    int64_t me = mb + rows_per_split;
+    me = me < M ? me : M;
+    const int nsteps = me > mb ? (int)((me - mb + 31) / 32) : 0;
+
+    f32x4 acc[4][6];
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    // ---- loader role of this wave: panel (wave >> 1) (0 = dY, 1..3 = X), rows rbase .. rbase + 15 of every stage
+    const int panel = wave >> 1, rbase = (wave & 1) * 16;
+    const int rsub = lane >> 4, cp = lane & 15;
+    const bf16* const pbase = panel == 0 ? dY : X;
+    const int64_t ld = panel == 0 ? lddy : ldx;
+    const int64_t col0 = panel == 0 ? n0 : kc0 + (panel - 1) * 128;
+    const int64_t colmax = panel == 0 ? N - 8 : col0 + 120;
+    int64_t coff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int64_t c = col0 + ((cp ^ tn_f(rbase + i * 4 + rsub)) << 3);
+        coff[i] = c <= colmax ? c : colmax;
+    }
+    auto issue = [&](int stage_idx) {   // stage_idx < nsteps
+        const int64_t mrow0 = mb + (int64_t)stage_idx * 32;
+        const bf16* src[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int64_t gm = mrow0 + rbase + i * 4 + rsub;
+            gm = gm < me ? gm : me - 1;          // clamped rows are zeroed in LDS after landing
+            src[i] = pbase + gm * ld + coff[i];
+        }
+        tw_stage_issue(src, smem + (stage_idx % TW_STAGES) * TW_STAGE_BYTES, panel, rbase);
+    };
+    // wait until this wave's pieces of stage `idx` have landed: the stages issued after it stay in flight
+    auto wait_landed = [&](int idx) {
+        const int later = (nsteps - 1 < idx + TW_STAGES - 2 ? nsteps - 1 : idx + TW_STAGES - 2) - idx;   // stages idx+1 .. issued so far
+        if (later >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * TW_PER) : "memory");
+        else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TW_PER) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (mb + (int64_t)(idx + 1) * 32 > me) {   // ragged last stage: zero the rows this lane's DMA clamped
+            char* st = smem + (idx % TW_STAGES) * TW_STAGE_BYTES;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = rbase + i * 4 + rsub;
+                if (mb + (int64_t)idx * 32 + r >= me) *(f32x4*)(st + panel * TW_PANEL_BYTES + r * 256 + cp * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    };
+
+    // ---- fragment offsets inside a stage (rows r_lo = 8g + q and r_lo + 4 of the 32-row step, as in the kernel above)
+    const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    const int r_lo = 8 * g + q, r_hi = r_lo + 4;
+    const int f_lo = tn_f(r_lo), f_hi = tn_f(r_hi);
+    int ya_lo[4], ya_hi[4], xb_lo[6], xb_hi[6];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ch = ((wr * 64 + i * 16) >> 3) + (p >> 1);
+        ya_lo[i] = r_lo * 256 + ((ch ^ f_lo) << 4) + 8 * (p & 1);
+        ya_hi[i] = r_hi * 256 + ((ch ^ f_hi) << 4) + 8 * (p & 1);
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int col = wc * 96 + j * 16;
+        const int ch = ((col & 127) >> 3) + (p >> 1);
+        const int base = (1 + (col >> 7)) * TW_PANEL_BYTES;
+        xb_lo[j] = base + r_lo * 256 + ((ch ^ f_lo) << 4) + 8 * (p & 1);
+        xb_hi[j] = base + r_hi * 256 + ((ch ^ f_hi) << 4) + 8 * (p & 1);
+    }
+
+    // Pipeline: the barrier of step t certifies stage t + 1 (landed) and frees stage t's slot (every wave holds its stage-t
+    // fragments in registers by then), so the fragment reads of step t + 1 are issued UNDER the MFMAs of step t and the MFMAs of
+    // consecutive steps run back to back: no LDS latency and no DMA issue on the critical path between two barriers.
+    auto step = [&](int t, const TwFrags& cur, TwFrags& nxt) {
+        if (t + 1 < nsteps) wait_landed(t + 1);
+        // the builtin (not inline asm) so that hipcc's own waitcnt bookkeeping knows the fragment reads have retired: with the asm
+        // form it re-waits for them in front of the MFMAs, behind the NEXT step's 20 reads (lgkmcnt saturates at 15)
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#ifndef TW_DBG_NO_DMA
+        if (t + TW_STAGES < nsteps) issue(t + TW_STAGES);     // into the slot stage t has just left
+#endif
+#ifdef TW_DBG_DMA_ONLY
+        return;
+#endif
+        if (t + 1 < nsteps) tw_read_frags(nxt, smem + ((t + 1) % TW_STAGES) * TW_STAGE_BYTES, ya_lo, ya_hi, xb_lo, xb_hi);
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)   // transposed product (X fragment as the A operand): a lane holds 4 consecutive k of one n row
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur.b[j], cur.a[i], acc[i][j], 0, 0, 0);
+        if (BIAS && kc0 == 0) {
+            typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+            const bf16x2_t one2 = {(__bf16)1.0f, (__bf16)1.0f};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    bsum[i] = __builtin_amdgcn_fdot2_f32_bf16(bf16x2_t{cur.a[i][2 * e], cur.a[i][2 * e + 1]}, one2, bsum[i], false);
+            }
+        }
+    };
+
+    if (nsteps > 0) {
+#pragma unroll
+        for (int pre = 0; pre < TW_STAGES; ++pre)
+            if (nsteps > pre) issue(pre);
+        // stage 0: landed for this wave, then for all
+        {
+            const int later = (nsteps - 1 < TW_STAGES - 1 ? nsteps - 1 : TW_STAGES - 1);
+            if (later >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * TW_PER) : "memory");
+            else if (later == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * TW_PER) : "memory");
+            else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TW_PER) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (mb + 32 > me) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = rbase + i * 4 + rsub;
+                    if (mb + r >= me) *(f32x4*)(smem + panel * TW_PANEL_BYTES + r * 256 + cp * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+        TwFrags fa, fb;
+#ifndef TW_DBG_DMA_ONLY
+        tw_read_frags(fa, smem, ya_lo, ya_hi, xb_lo, xb_hi);
+#endif
+        for (int t = 0; t < nsteps; t += 2) {
+            step(t, fa, fb);
+            if (t + 1 < nsteps) step(t + 1, fb, fa);
+        }
+    }
+
+    float* o = out + (int64_t)split * N * K;
+    const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t n = n0 + wr * 64 + i * 16 + fr;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int64_t k = kc0 + wc * 96 + j * 16 + fq * 4;
+            if (n < N) *(f32x4*)(o + n * K + k) = acc[i][j];
+        }
+    }
+    if constexpr (BIAS) {
+        if (kc0 == 0 && wc == 0) {
+            float* bo = bias_out + (int64_t)split * N;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v = bsum[i];
+                v += __shfl_xor(v, 16);
+                v += __shfl_xor(v, 32);
+                const int64_t n = n0 + wr * 64 + i * 16 + fr;
+                if (fq == 0 && n < N) bo[n] = v;
+            }
+        }
+    }
+}
+
 bool gemm_tn_mfma_supported(const void* dY, int64_t lddy, const void* X, int64_t ldx, int64_t M, int64_t N, int64_t K) {
     auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
     return N % 8 == 0 && K % 8 == 0 && N >= 8 && K >= 8 && lddy % 8 == 0 && ldx % 8 == 0 && al16(dY) && al16(X) && M >= 1;
@@ -533,7 +753,26 @@ static inline bool tn_use_ring(int64_t M, int64_t N, int64_t K) {
 
 // Splits over M: as many as fill the chip's resident workgroup slots (2 per CU at 64 KB of LDS, 3 per CU at 48 KB)
 // in ONE round - one workgroup more than a round costs a whole extra round.
+// The wide tile pays once a split is long enough to amortise its ring fill and its 192 KB slab (M >= 4,096 rows).
+static inline bool tn_use_wide(int64_t M, int64_t N, int64_t K) {
+    if (TN_FORCE_TM) return false;
+    static const char* env = getenv("VITED_TN_WIDE");           // tuning override: 0 = never, 1 = whenever the shape allows
+    if (K % 384 != 0) return false;
+    if (env) return atoi(env) != 0;
+    return M >= 4096;
+}
+
 int64_t gemm_tn_mfma_splits(int64_t M, int64_t N, int64_t K) {
+    if (tn_use_wide(M, N, K)) {   // one workgroup per CU, one round
+        const int64_t tiles = ceil_div64(N, 128) * (K / 384);
+        static const int64_t slots_env = getenv("VITED_TN_WIDE_SLOTS") ? atoi(getenv("VITED_TN_WIDE_SLOTS")) : 0;
+        int64_t s = (slots_env ? slots_env : 256) / tiles;
+        const int64_t max_s = ceil_div64(M, 256);
+        if (s > max_s) s = max_s;
+        if (s < 1) s = 1;
+        const int64_t rps = ceil_div64(ceil_div64(M, s), 32) * 32;
+        return ceil_div64(M, rps);
+    }
     const bool ring = tn_use_ring(M, N, K);
     const int tm = TN_FORCE_TM ? TN_FORCE_TM : (ring ? 32 : 64);
     const int64_t tiles = ceil_div64(N, 128) * ceil_div64(K, 128);
@@ -570,8 +809,32 @@ static void launch_tn(const void* dY, int64_t lddy, const void* X, int64_t ldx, 
                            (const bf16*)dY, lddy, (const bf16*)X, ldx, M, N, K, rps, tiles_k, out, bias_out);
 }
 
+static void launch_tn_wide(const void* dY, int64_t lddy, const void* X, int64_t ldx, int64_t M, int64_t N, int64_t K, int64_t splits,
+                           float* out, float* bias_out, hipStream_t s) {
+    constexpr int LDS = TW_STAGES * TW_STAGE_BYTES;
+    const int tiles_k = (int)(K / 384);
+    const int tiles = (int)ceil_div64(N, 128) * tiles_k;
+    const int64_t rps = ceil_div64(ceil_div64(M, splits), 32) * 32;
+    static bool done = false;
+    if (!done) {
+        hipFuncSetAttribute((const void*)gemm_tn_wide_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipFuncSetAttribute((const void*)gemm_tn_wide_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        done = true;
+    }
+    if (bias_out)
+        hipLaunchKernelGGL((gemm_tn_wide_kernel<true>), dim3(tiles, (unsigned)splits), dim3(512), LDS, s, (const bf16*)dY, lddy,
+                           (const bf16*)X, ldx, M, N, K, rps, tiles_k, out, bias_out);
+    else
+        hipLaunchKernelGGL((gemm_tn_wide_kernel<false>), dim3(tiles, (unsigned)splits), dim3(512), LDS, s, (const bf16*)dY, lddy,
+                           (const bf16*)X, ldx, M, N, K, rps, tiles_k, out, bias_out);
+}
+
 int gemm_tn_mfma(const void* dY, int64_t lddy, const void* X, int64_t ldx, int64_t M, int64_t N, int64_t K, int64_t splits,
                  float* out, float* bias_out, hipStream_t s) {
+    if (tn_use_wide(M, N, K)) {
+        launch_tn_wide(dY, lddy, X, ldx, M, N, K, splits, out, bias_out, s);
+        return vited_check_launch();
+    }
 #if TN_FORCE_TM
     launch_tn<TN_FORCE_TM, TN_FORCE_STAGES>(dY, lddy, X, ldx, M, N, K, splits, out, bias_out, s);
 #else
