@@ -599,16 +599,30 @@ gemm_tn_wide_kernel(const bf16* __restrict__ dY, int64_t lddy, const bf16* __res
         int64_t c = col0 + ((cp ^ tn_f(rbase + i * 4 + rsub)) << 3);
         coff[i] = c <= colmax ? c : colmax;
     }
-    auto issue = [&](int stage_idx) {   // stage_idx < nsteps
-        const int64_t mrow0 = mb + (int64_t)stage_idx * 32;
-        const bf16* src[4];
+    // source pointers of stage 0 (rows unclamped); a full stage s reads 32 s rows further down: two VALU adds per piece, the
+    // 64-bit row multiply and the clamp stay off the loop (only the ragged last stage re-derives its rows)
+    const bf16* p0[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int64_t gm = mrow0 + rbase + i * 4 + rsub;
-            gm = gm < me ? gm : me - 1;          // clamped rows are zeroed in LDS after landing
-            src[i] = pbase + gm * ld + coff[i];
+    for (int i = 0; i < 4; ++i) p0[i] = pbase + (mb + rbase + i * 4 + rsub) * ld + coff[i];
+    const int64_t stage_stride = 32 * ld;
+    auto issue = [&](int stage_idx) {   // stage_idx < nsteps
+        char* dst = smem + (stage_idx % TW_STAGES) * TW_STAGE_BYTES;
+        if (mb + (int64_t)(stage_idx + 1) * 32 <= me) {   // a real (scalar) branch: each arm issues its own DMA
+            const int64_t adv = (int64_t)stage_idx * stage_stride;    // wave-uniform
+            const bf16* src[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) src[i] = p0[i] + adv;
+            tw_stage_issue(src, dst, panel, rbase);
+        } else {
+            const bf16* src[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int64_t gm = mb + (int64_t)stage_idx * 32 + rbase + i * 4 + rsub;
+                gm = gm < me ? gm : me - 1;          // clamped rows are zeroed in LDS after landing
+                src[i] = pbase + gm * ld + coff[i];
+            }
+            tw_stage_issue(src, dst, panel, rbase);
         }
-        tw_stage_issue(src, smem + (stage_idx % TW_STAGES) * TW_STAGE_BYTES, panel, rbase);
     };
     // wait until this wave's pieces of stage `idx` have landed: the stages issued after it stay in flight
     auto wait_landed = [&](int idx) {
@@ -656,18 +670,28 @@ gemm_tn_wide_kernel(const bf16* __restrict__ dY, int64_t lddy, const bf16* __res
         __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        // The two waves of a SIMD (w and w + 4) take the step's two jobs in opposite order - one issues the next stage's DMA
+        // (address VALU + 4 LDS-DMA pieces) while the other's 24 MFMAs hold the matrix pipe, then they swap - instead of both
+        // issuing DMA together and then queueing on the MFMA pipe.
+        const bool dma_first = (wave >> 2) != 0;
 #ifndef TW_DBG_NO_DMA
-        if (t + TW_STAGES < nsteps) issue(t + TW_STAGES);     // into the slot stage t has just left
+        if (dma_first && t + TW_STAGES < nsteps) issue(t + TW_STAGES);     // into the slot stage t has just left
 #endif
 #ifdef TW_DBG_DMA_ONLY
+        if (!dma_first && t + TW_STAGES < nsteps) issue(t + TW_STAGES);
         return;
 #endif
         if (t + 1 < nsteps) tw_read_frags(nxt, smem + ((t + 1) % TW_STAGES) * TW_STAGE_BYTES, ya_lo, ya_hi, xb_lo, xb_hi);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 6; ++j)
 #pragma unroll
             for (int i = 0; i < 4; ++i)   // transposed product (X fragment as the A operand): a lane holds 4 consecutive k of one n row
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur.b[j], cur.a[i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#ifndef TW_DBG_NO_DMA
+        if (!dma_first && t + TW_STAGES < nsteps) issue(t + TW_STAGES);
+#endif
         if (BIAS && kc0 == 0) {
             typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
             const bf16x2_t one2 = {(__bf16)1.0f, (__bf16)1.0f};
