@@ -17,9 +17,12 @@ Workloads (BASELINE.json ``configs``):
 
 One JSON line on rank 0 (contract in the task statement).  Extra objects:
   roofline      dominant kernel class (by summed device time), timed live with HIP events on the launch stream during an
-                instrumented eager pass of the same step; achieved = algorithmic FLOPs of those launches / their summed
-                duration; peak = 2500 TFLOP/s dense bf16 (MI355X_MICROARCH.md), with the peak derived from this box's
-                rocminfo (CUs x 4 SIMD x 1024 FLOP/clk x max clock) recorded beside it.
+                instrumented eager pass of the same step.  Both roofs are evaluated from the launches' ALGORITHMIC work
+                (FLOPs, and operand + result bytes counted once: DESIGN.md section 4) over their summed duration - against
+                2500 TFLOP/s dense bf16 and 8000 GB/s HBM (MI355X_MICROARCH.md); ``bound`` / ``achieved`` / ``peak`` /
+                ``frac`` are the roof the class sits closer to and ``other_roof`` is the second one.  ``traffic`` = measured
+                HBM bytes per launch from the committed rocprofv3 PMC passes; ``step_algorithmic_bytes`` = the same byte count
+                over every instrumented launch of the step (GEMMs, weight gradients, attention, LayerNorm).
   cpu_baseline  the fp32 CPU oracle (oracle/vited_oracle.py, a port - the reference itself cannot travel) on a bounded
                 sample: config A, batch 32, fwd+bwd, median of 5 steps, with the host's CPU model and thread count.
 """
@@ -38,6 +41,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_DENSE_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PF dense bf16 (never the 2:1-sparse figure)
+PEAK_HBM_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 CFG_A = os.path.join(ROOT, 'configs', 'puzzle', 'div2k_erosion7_4bin_patch8_64.yaml')
 CFG_H = os.path.join(ROOT, 'configs', 'hisfrag', 'hisfrag20_patch16_512.yaml')
 PMC_TRAFFIC_CSV = os.path.join(ROOT, 'profiles', 'r02_hbm_traffic_per_kernel.csv')
@@ -204,8 +208,27 @@ class LaunchTimer:
             n = B.shape[0] if k.get('b_layout', 0) == 0 else B.shape[1]
             es = A.element_size()
             epi = k.get('epilogue', 0)
-            out = {0: es, 1: 2 * es, 2: 4 + 4, 3: es + es, 4: 4}.get(epi, es)   # store | two outputs | residual in + fp32 out | aux in + out | fp32
+            # per output element: store | GELU: two outputs | residual in + fp32 out | aux in + out | fp32 out | aux in + out | two outputs
+            out = {0: es, 1: 2 * es, 2: 4 + 4, 3: es + es, 4: 4, 5: es + es, 6: 2 * es}.get(epi, es)
             return float(m * kk * es + n * kk * es + m * n * out)
+
+        def tn_bytes(a, k):     # both operands once + the fp32 result (the split-M slabs are workspace traffic, not algorithmic)
+            dy, x = a[0], a[1]
+            return float(dy.numel() * dy.element_size() + x.numel() * x.element_size() + 4 * dy.shape[1] * x.shape[1])
+
+        def attn_bytes(a, k, bwd=False):   # q, k, v (+ o, do) in, o (or dq, dk, dv) out
+            q, kk, v = a[0], a[1], a[2]
+            io = sum(t.numel() * t.element_size() for t in (q, kk, v))
+            return float(2 * io + q.numel() * q.element_size()) if bwd else float(io + q.numel() * q.element_size())
+
+        def ln_fwd_bytes(a, k):
+            x = a[0]
+            return float(x.numel() * (4 + 2))
+
+        def ln_bwd_bytes(a, k):   # dy (act dtype), x, dx_in fp32 in; dx fp32 (+ low-precision copy) out
+            dy, x = a[0], a[1]
+            n = x.numel()
+            return float(n * (dy.element_size() + 4 + (4 if k.get('dx_in') is not None else 0) + 4 + (2 if (k.get('want_lp') or k.get('dx_lp') is not None) else 0)))
 
         def tn_flops(a, k):
             dy, x = a[0], a[1]
@@ -216,9 +239,12 @@ class LaunchTimer:
             return 4.0 * q.shape[0] * q.shape[1] * kk.shape[1] * q.shape[2]
 
         self._wrap('gemm', gemm_flops, lambda a, k, gp, ap: 'gemm_nt_mfma_kernel' if gp == 2 else 'gemm_portable_kernel', gemm_bytes)
-        self._wrap('linear_bwd_weight', tn_flops, lambda a, k, gp, ap: 'gemm_tn_mfma_kernel(+slab/bias sums)' if gp == 2 else 'gemm_tn_portable_kernel')
-        self._wrap('attention_fwd', attn_fwd_flops, lambda a, k, gp, ap: 'attn_fwd_mfma' if ap == 2 else 'attn_fwd_portable_kernel')
-        self._wrap('attention_bwd', lambda a, k: 2.5 * attn_fwd_flops(a, k), lambda a, k, gp, ap: 'attn_bwd_mfma' if ap == 2 else 'attn_bwd_portable_kernels')
+        self._wrap('linear_bwd_weight', tn_flops, lambda a, k, gp, ap: 'gemm_tn_mfma_kernel(+slab/bias sums)' if gp == 2 else 'gemm_tn_portable_kernel', tn_bytes)
+        self._wrap('attention_fwd', attn_fwd_flops, lambda a, k, gp, ap: 'attn_fwd_mfma' if ap == 2 else 'attn_fwd_portable_kernel', attn_bytes)
+        self._wrap('attention_bwd', lambda a, k: 2.5 * attn_fwd_flops(a, k), lambda a, k, gp, ap: 'attn_bwd_mfma' if ap == 2 else 'attn_bwd_portable_kernels',
+                   lambda a, k: attn_bytes(a, k, True))
+        self._wrap('layernorm_fwd', lambda a, k: 0.0, lambda a, k, gp, ap: 'layernorm_fwd_kernel', ln_fwd_bytes)
+        self._wrap('layernorm_bwd', lambda a, k: 0.0, lambda a, k, gp, ap: 'layernorm_bwd_kernel', ln_bwd_bytes)
         if hasattr(self.ops, 'mlp_fwd'):
             self._wrap('mlp_fwd', lambda a, k: 4.0 * a[0].shape[0] * a[0].shape[1] * a[3].shape[0], lambda a, k, gp, ap: 'mlp_fwd_fused_kernel')
         return self
@@ -248,16 +274,25 @@ def roofline_of(V, run_once, passes=2):
             run_once()
         agg = lt.summary()
     kernels = {k: {'launches': v['launches'], 'avg_us': round(1e3 * v['ms'] / v['launches'], 2),
-                   'total_ms_per_step': round(v['ms'] / passes, 3), 'tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 1)}
+                   'total_ms_per_step': round(v['ms'] / passes, 3), 'tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 1),
+                   'algorithmic_TBps': round(v['bytes'] / (v['ms'] * 1e-3) / 1e12, 2)}
                for k, v in sorted(agg.items(), key=lambda kv: -kv[1]['ms'])}
     dom = next(iter(kernels))
     d = agg[dom]
-    achieved = d['flops'] / (d['ms'] * 1e-3) / 1e12
+    secs = d['ms'] * 1e-3
+    tflops, tbps = d['flops'] / secs / 1e12, d['bytes'] / secs / 1e12
     derived = rocminfo_peak()
-    roof = {'bound': 'mfma', 'kernel': dom, 'achieved': round(achieved, 1), 'peak': PEAK_BF16_DENSE_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': round(achieved / PEAK_BF16_DENSE_TFLOPS, 4), 'peak_from_rocminfo': derived,
+    mfma = {'bound': 'mfma', 'achieved': round(tflops, 1), 'peak': PEAK_BF16_DENSE_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': round(tflops / PEAK_BF16_DENSE_TFLOPS, 4)}
+    hbm = {'bound': 'hbm', 'achieved': round(tbps * 1e3, 1), 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s', 'frac': round(tbps * 1e3 / PEAK_HBM_GBPS, 4)}
+    # the roof that binds is the one the kernel class sits closer to; the other one is reported beside it
+    first, second = (hbm, mfma) if hbm['frac'] >= mfma['frac'] else (mfma, hbm)
+    roof = {**first, 'kernel': dom, 'other_roof': second, 'peak_from_rocminfo': derived,
             'avg_launch_us': round(1e3 * d['ms'] / d['launches'], 2), 'launches_per_step': d['launches'] // passes,
-            'algorithmic_bytes_per_launch': round(d['bytes'] / d['launches']), **pmc_traffic(dom)}
+            'algorithmic_bytes_per_launch': round(d['bytes'] / d['launches']),
+            'algorithmic_flops_per_launch': round(d['flops'] / d['launches']), **pmc_traffic(dom)}
+    # all instrumented launches of one step (GEMMs, dW, attention, LayerNorm): the unfused dataflow's own HBM bytes
+    roof['step_algorithmic_bytes'] = round(sum(v['bytes'] for v in agg.values()) / passes)
     return {'roofline': roof, 'kernels': kernels}
 
 

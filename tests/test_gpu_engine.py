@@ -202,3 +202,60 @@ def test_two_ranks_on_one_gpu_match_single_process(vited, gpu, tmp_path):
     for k, v in m.state_dict().items():
         # mean of the two shard gradients == full-batch gradient up to fp32 summation order; AdamW amplifies that on ~0 gradients
         torch.testing.assert_close(res['state'][k], v.cpu(), rtol=1e-3, atol=2e-4, msg=lambda msg: f'{k}: {msg}')
+
+
+# ---------------------------------------------------------------------------------------------
+# RCCL itself on the one GPU there is: a one-rank "nccl" group with the collectives forced on, so the calls the 8-GPU run
+# will make (ReduceOp.AVG on slices of the flat fp32 buffer, async work handles joined before the update graph, the
+# flat broadcast) run through RCCL between the hipGraph replays.  The mean over one rank is the identity: results must be
+# bit-identical to the same steps without a process group.
+# ---------------------------------------------------------------------------------------------
+def _rccl_one_rank(rank, port, out):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+    import vited_amd as V
+    dev = torch.device('cuda:0')
+    torch.cuda.set_device(dev)
+    s = vo.ViTEDShape(depth=1, c_depth=1)
+
+    def run(distributed):
+        torch.manual_seed(5)
+        m = V.VisionTransformerCustom(img_size=s.img_size, patch_size=s.patch_size, num_classes=s.num_classes, embed_dim=s.embed_dim,
+                                      depth=1, c_depth=1, num_heads=s.num_heads).to(dev)
+        m.compute_dtype = torch.bfloat16
+        if distributed:
+            V.engine.broadcast_parameters(m)
+        opt = V.optim.FlatAdamW(V.engine.param_groups_no_decay_1d(m), lr=1e-3, weight_decay=0.05)
+        step = V.engine.TrainStep(m, opt, clip_grad=5.0, amp=True, use_graph=True)
+        g = torch.Generator().manual_seed(7)
+        losses = []
+        for it in range(5):
+            x = torch.randn(8, 2, 3, 64, 64, generator=g).clamp(-1, 1)
+            y = (torch.rand(8, 4, generator=g) > 0.6).float()
+            losses.append(float(step.step(x.to(dev), y.to(dev))))
+        return torch.cat([p.detach().reshape(-1) for p in m.parameters()]).cpu(), losses
+
+    ref, ref_losses = run(False)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', VITED_FORCE_COLLECTIVE='1')
+    dist.init_process_group('nccl', init_method='env://', world_size=1, rank=0, device_id=dev)
+    calls = {'n': 0}
+    orig = dist.all_reduce
+
+    def counting(*a, **k):
+        calls['n'] += 1
+        return orig(*a, **k)
+    dist.all_reduce = counting
+    got, losses = run(True)
+    dist.all_reduce = orig
+    torch.cuda.synchronize()
+    dist.destroy_process_group()
+    torch.save({'equal': bool(torch.equal(ref, got)), 'losses': losses == ref_losses, 'calls': calls['n']}, out)
+
+
+def test_rccl_one_rank_collectives_between_graph_replays(vited, gpu, tmp_path):
+    out = str(tmp_path / 'rccl.pt')
+    mp.spawn(_rccl_one_rank, args=(29900 + os.getpid() % 90, out), nprocs=1, join=True)
+    res = torch.load(out, weights_only=True)
+    assert res['calls'] == 10           # two buckets x five steps went through RCCL
+    assert res['equal'] and res['losses']

@@ -681,13 +681,20 @@ gemm_tn_wide_kernel(const bf16* __restrict__ dY, int64_t lddy, const bf16* __res
         if (!dma_first && t + TW_STAGES < nsteps) issue(t + TW_STAGES);
         return;
 #endif
+#ifndef TW_DBG_NO_READS
         if (t + 1 < nsteps) tw_read_frags(nxt, smem + ((t + 1) % TW_STAGES) * TW_STAGE_BYTES, ya_lo, ya_hi, xb_lo, xb_hi);
+#endif
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 6; ++j)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)   // transposed product (X fragment as the A operand): a lane holds 4 consecutive k of one n row
+            for (int i = 0; i < 4; ++i) {  // transposed product (X fragment as the A operand): a lane holds 4 consecutive k of one n row
+#ifdef TW_DBG_NO_MFMA
+                asm volatile("" ::"v"(cur.b[j]), "v"(cur.a[i]));
+#else
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur.b[j], cur.a[i], acc[i][j], 0, 0, 0);
+#endif
+            }
         __builtin_amdgcn_sched_barrier(0);
 #ifndef TW_DBG_NO_DMA
         if (!dma_first && t + TW_STAGES < nsteps) issue(t + TW_STAGES);

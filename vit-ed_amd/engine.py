@@ -117,7 +117,10 @@ class FlatGradients:
         group's own stream behind everything already queued on the current stream).  ``finish_all_reduce``
         joins."""
         world = dist.get_world_size(group) if dist.is_initialized() else 1
-        if world == 1 or hi <= lo:
+        # VITED_FORCE_COLLECTIVE=1: issue the collective on a one-rank group too (a one-GPU box can then exercise the RCCL calls and
+        # their ordering against the graph replays; the mean over one rank is the identity)
+        force = world == 1 and dist.is_initialized() and os.environ.get('VITED_FORCE_COLLECTIVE') == '1'
+        if (world == 1 and not force) or hi <= lo:
             return
         seg = self.flat[lo:hi]
         if self.wire is not None:
