@@ -252,7 +252,7 @@ static void launch_nt(const bf16* a, int64_t lda, const bf16* b, int64_t ldb, in
     if (LDS > 65536) {
         static bool done = false;
         if (!done) {
-            hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+            (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
             done = true;
         }
     }
@@ -529,7 +529,9 @@ gemm_tn_mfma_kernel(const bf16* __restrict__ dY, int64_t lddy, const bf16* __res
 // three stages (96 KB) in flight per CU across the barrier - counted vmcnt, raw s_barrier, LDS-DMA from inline asm.
 // Taken when K is a multiple of 384 (every dW of the embed-384 models: qkv / kv / proj / fc1 / fc2).
 // ================================================================================================
+#ifndef TW_STAGES
 #define TW_STAGES 4
+#endif
 #define TW_PANEL_BYTES (32 * 256)
 #define TW_STAGE_BYTES (4 * TW_PANEL_BYTES)
 #define TW_PER 4   // LDS-DMA instructions per stage per wave
@@ -627,7 +629,8 @@ gemm_tn_wide_kernel(const bf16* __restrict__ dY, int64_t lddy, const bf16* __res
     // wait until this wave's pieces of stage `idx` have landed: the stages issued after it stay in flight
     auto wait_landed = [&](int idx) {
         const int later = (nsteps - 1 < idx + TW_STAGES - 2 ? nsteps - 1 : idx + TW_STAGES - 2) - idx;   // stages idx+1 .. issued so far
-        if (later >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * TW_PER) : "memory");
+        if (later >= 3 && TW_STAGES > 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * TW_PER) : "memory");
+        else if (later >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * TW_PER) : "memory");
         else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TW_PER) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (mb + (int64_t)(idx + 1) * 32 > me) {   // ragged last stage: zero the rows this lane's DMA clamped
@@ -718,7 +721,8 @@ gemm_tn_wide_kernel(const bf16* __restrict__ dY, int64_t lddy, const bf16* __res
         // stage 0: landed for this wave, then for all
         {
             const int later = (nsteps - 1 < TW_STAGES - 1 ? nsteps - 1 : TW_STAGES - 1);
-            if (later >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * TW_PER) : "memory");
+            if (later >= 4 && TW_STAGES > 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * TW_PER) : "memory");
+            else if (later >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * TW_PER) : "memory");
             else if (later == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * TW_PER) : "memory");
             else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TW_PER) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -827,8 +831,8 @@ static void launch_tn(const void* dY, int64_t lddy, const void* X, int64_t ldx, 
     if (LDS > 65536) {   // dynamic LDS above 64 KB needs the opt-in (once per kernel)
         static bool done = false;
         if (!done) {
-            hipFuncSetAttribute((const void*)gemm_tn_mfma_kernel<true, TM, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-            hipFuncSetAttribute((const void*)gemm_tn_mfma_kernel<false, TM, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+            (void)hipFuncSetAttribute((const void*)gemm_tn_mfma_kernel<true, TM, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+            (void)hipFuncSetAttribute((const void*)gemm_tn_mfma_kernel<false, TM, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
             done = true;
         }
     }
@@ -848,8 +852,8 @@ static void launch_tn_wide(const void* dY, int64_t lddy, const void* X, int64_t 
     const int64_t rps = ceil_div64(ceil_div64(M, splits), 32) * 32;
     static bool done = false;
     if (!done) {
-        hipFuncSetAttribute((const void*)gemm_tn_wide_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        hipFuncSetAttribute((const void*)gemm_tn_wide_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_tn_wide_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_tn_wide_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         done = true;
     }
     if (bias_out)
