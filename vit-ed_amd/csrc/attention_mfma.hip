@@ -151,7 +151,10 @@ template <int HD, int NQT, int NKT> struct BwdSmallLds {
 };
 
 template <int HD, int NQT, int NKT>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3)))   // <= 168 VGPRs: 3 workgroups per CU (4 would spill)
+#ifndef ATTN_BWD_WAVES_PER_EU
+#define ATTN_BWD_WAVES_PER_EU 3
+#endif
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ATTN_BWD_WAVES_PER_EU)))   // <= 168 VGPRs: 3 workgroups per CU (4 would spill)
 attn_bwd_small_kernel(AttnArgs a) {
     using C = SmallCfg<HD>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
