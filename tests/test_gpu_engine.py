@@ -259,3 +259,58 @@ def test_rccl_one_rank_collectives_between_graph_replays(vited, gpu, tmp_path):
     res = torch.load(out, weights_only=True)
     assert res['calls'] == 10           # two buckets x five steps went through RCCL
     assert res['equal'] and res['losses']
+
+
+# ---------------------------------------------------------------------------------------------
+# the reference's own wrap (misc/engine.py:75): torch DistributedDataParallel around the HIP model, driven by the reference's
+# loop order (autocast forward, scaler(loss, optimizer, clip_grad, parameters), optimizer.zero_grad() - misc/engine.py:208-231)
+# ---------------------------------------------------------------------------------------------
+def _ddp_rank(rank, world, port, out):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+    import vited_amd as V
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0')
+    dist.init_process_group('gloo', init_method='env://', world_size=world, rank=rank)
+    dev = torch.device('cuda:0')
+    torch.cuda.set_device(dev)
+    s = vo.ViTEDShape(depth=1, c_depth=1)
+    torch.manual_seed(300 + rank)                     # DDP's ctor broadcasts rank 0's parameters
+    m = V.VisionTransformerCustom(img_size=s.img_size, patch_size=s.patch_size, num_classes=s.num_classes, embed_dim=s.embed_dim,
+                                  depth=1, c_depth=1, num_heads=s.num_heads).to(dev)
+    m.compute_dtype = torch.float32
+    ddp = torch.nn.parallel.DistributedDataParallel(m, device_ids=[0], broadcast_buffers=False)
+    opt = torch.optim.AdamW(V.engine.param_groups_no_decay_1d(m), lr=1e-3, weight_decay=0.05)
+    scaler = V.engine.NativeScalerWithGradNormCount()
+    g = torch.Generator().manual_seed(11)
+    for it in range(3):
+        x = torch.randn(8, 2, 3, 64, 64, generator=g).clamp(-1, 1)
+        y = (torch.rand(8, 4, generator=g) > 0.6).float()
+        loss = bce(ddp(x[rank::world].to(dev)).float(), y[rank::world].to(dev))
+        scaler(loss, opt, clip_grad=5.0, parameters=ddp.parameters())
+        opt.zero_grad()
+    if rank == 0:
+        torch.save({k: v.cpu() for k, v in m.state_dict().items()}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_hip_model_under_torch_ddp_wrap_matches_single_process(vited, gpu, tmp_path):
+    out = str(tmp_path / 'ddp.pt')
+    mp.spawn(_ddp_rank, args=(2, 29500 + os.getpid() % 150, out), nprocs=2, join=True)
+    got = torch.load(out, weights_only=True)
+    s = vo.ViTEDShape(depth=1, c_depth=1)
+    torch.manual_seed(300)
+    m = _hip_model(vited, s, gpu, torch.float32)
+    opt = torch.optim.AdamW(vited.engine.param_groups_no_decay_1d(m), lr=1e-3, weight_decay=0.05)
+    scaler = vited.engine.NativeScalerWithGradNormCount()
+    g = torch.Generator().manual_seed(11)
+    for it in range(3):
+        x = torch.randn(8, 2, 3, 64, 64, generator=g).clamp(-1, 1)
+        y = (torch.rand(8, 4, generator=g) > 0.6).float()
+        loss = bce(m(x.to(gpu)).float(), y.to(gpu))
+        scaler(loss, opt, clip_grad=5.0, parameters=m.parameters())
+        opt.zero_grad()
+    for k, v in m.state_dict().items():
+        # DDP averages the two shard gradients: the full-batch gradient up to fp32 summation order (AdamW amplifies that on ~0 gradients)
+        torch.testing.assert_close(got[k], v.cpu(), rtol=1e-3, atol=2e-4, msg=lambda msg: f'{k}: {msg}')
