@@ -31,29 +31,52 @@ template <int HD> struct FlashCfg {
     static constexpr int PASSES = FL_TILE * CHUNKS_PER_ROW / 256;   // 16-byte chunks per thread and tile
 };
 
-// cooperative tile copy, global -> registers (rows clamped to n-1) ...
+// This thread's 16-byte chunks of a 64-row tile: what does not change from tile to tile (the loops below are VALU-bound - PMC:
+// 8 vector instructions per MFMA in the forward - and the staging arithmetic redone per tile was a third of them: row clamp as
+// compare + select, 64-bit row * stride, the swizzle, a select per stored dword).
+template <int HD> struct TileMap {
+    int row[FlashCfg<HD>::PASSES];   // row inside the tile
+    int col2[FlashCfg<HD>::PASSES];  // column, in bytes
+    int loff[FlashCfg<HD>::PASSES];  // byte offset inside the swizzled LDS image
+    __device__ __forceinline__ TileMap(int tid) {
+#pragma unroll
+        for (int c = 0; c < FlashCfg<HD>::PASSES; ++c) {
+            const int idx = tid + 256 * c;
+            const int ch = idx % FlashCfg<HD>::CHUNKS_PER_ROW;
+            row[c] = idx / FlashCfg<HD>::CHUNKS_PER_ROW;
+            col2[c] = ch * 16;
+            loff[c] = SmallCfg<HD>::off(row[c], ch * 16);
+        }
+    }
+};
+// cooperative tile copy, global -> registers.  Rows past n - 1 re-read row n - 1 (finite values; regs_to_tile zeroes them): the
+// clamp is one v_min against a wave-uniform bound and the address is a 64-bit uniform tile base + a 32-bit per-lane byte offset
+// (attention_fwd_flash / attention_bwd_flash refuse token strides of 2^24 elements or more) ...
 template <int HD>
-__device__ __forceinline__ void tile_to_regs(const bf16* base, int64_t ts, int row0, int n, int tid, bf16x8 (&r)[FlashCfg<HD>::PASSES]) {
+__device__ __forceinline__ void tile_to_regs(const bf16* base, int64_t ts, int row0, int n, const TileMap<HD>& m, bf16x8 (&r)[FlashCfg<HD>::PASSES]) {
+    const char* tb = (const char*)(base + (int64_t)row0 * ts);   // wave-uniform
+    const int last = n - 1 - row0;                               // >= 0: a tile is only staged when it holds a valid row
+    const unsigned ts2 = (unsigned)ts * 2u;
 #pragma unroll
     for (int c = 0; c < FlashCfg<HD>::PASSES; ++c) {
-        const int idx = tid + 256 * c;
-        const int row = idx / FlashCfg<HD>::CHUNKS_PER_ROW, ch = idx % FlashCfg<HD>::CHUNKS_PER_ROW;
-        int rr = row0 + row;
-        rr = rr < n ? rr : n - 1;
-        r[c] = *(const bf16x8*)(base + (int64_t)rr * ts + ch * 8);
+        const unsigned rr = (unsigned)(m.row[c] < last ? m.row[c] : last);
+        r[c] = *(const bf16x8*)(tb + (rr * ts2 + (unsigned)m.col2[c]));
     }
 }
-// ... and registers -> LDS image (rows >= n zeroed)
+// ... and registers -> LDS image (rows >= n zeroed; only the ragged last tile pays for the selects)
 template <int HD>
-__device__ __forceinline__ void regs_to_tile(char* lds, int row0, int n, int tid, const bf16x8 (&r)[FlashCfg<HD>::PASSES]) {
-    const bool ragged = row0 + FL_TILE > n;   // uniform: full tiles skip the per-row select
+__device__ __forceinline__ void regs_to_tile(char* lds, int row0, int n, const TileMap<HD>& m, const bf16x8 (&r)[FlashCfg<HD>::PASSES]) {
+    if (row0 + FL_TILE > n) {   // wave-uniform
+        asm volatile("" ::: "memory");   // keep this a branch: if-converted it costs a select per stored dword on EVERY tile
 #pragma unroll
-    for (int c = 0; c < FlashCfg<HD>::PASSES; ++c) {
-        const int idx = tid + 256 * c;
-        const int row = idx / FlashCfg<HD>::CHUNKS_PER_ROW, ch = idx % FlashCfg<HD>::CHUNKS_PER_ROW;
-        bf16x8 v = r[c];
-        if (ragged && row0 + row >= n) v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-        *(bf16x8*)(lds + SmallCfg<HD>::off(row, ch * 16)) = v;
+        for (int c = 0; c < FlashCfg<HD>::PASSES; ++c) {
+            bf16x8 v = r[c];
+            if (row0 + m.row[c] >= n) v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            *(bf16x8*)(lds + m.loff[c]) = v;
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < FlashCfg<HD>::PASSES; ++c) *(bf16x8*)(lds + m.loff[c]) = r[c];
     }
 }
 // MFMA row fragment (row fr of 16-row tile t, k chunk g + 4c) out of an LDS image
@@ -107,17 +130,21 @@ attn_fwd_flash_kernel(AttnArgs a) {
     }
     const int ntiles = (nk + FL_TILE - 1) / FL_TILE;
     bf16x8 kr[F::PASSES], vr[F::PASSES];
-    tile_to_regs<HD>(kb, a.k_ts, 0, nk, tid, kr);
-    tile_to_regs<HD>(vb, a.v_ts, 0, nk, tid, vr);
-    regs_to_tile<HD>(smem, 0, nk, tid, kr);
-    regs_to_tile<HD>(smem + F::TILE_BYTES, 0, nk, tid, vr);
+    const TileMap<HD> mk(tid);
+    const TileMap<HD>& mv = mk;
+    tile_to_regs<HD>(kb, a.k_ts, 0, nk, mk, kr);
+    tile_to_regs<HD>(vb, a.v_ts, 0, nk, mv, vr);
+    regs_to_tile<HD>(smem, 0, nk, mk, kr);
+    regs_to_tile<HD>(smem + F::TILE_BYTES, 0, nk, mv, vr);
     __syncthreads();
-    for (int t = 0; t < ntiles; ++t) {
+    // One tile = one call of `iteration`.  The ragged last tile is PEELED out of the loop (second instantiation below) instead of
+    // being a branch inside it: with two bodies merging inside the loop hipcc copied all 32 O accumulators at every back-edge.
+    auto iteration = [&](int t, auto ragged_tag) {
         const char* ks = smem + (t & 1) * 2 * F::TILE_BYTES;
         const char* vs = ks + F::TILE_BYTES;
         if (t + 1 < ntiles) {   // next tile: loads fly under this tile's MFMAs
-            tile_to_regs<HD>(kb, a.k_ts, (t + 1) * FL_TILE, nk, tid, kr);
-            tile_to_regs<HD>(vb, a.v_ts, (t + 1) * FL_TILE, nk, tid, vr);
+            tile_to_regs<HD>(kb, a.k_ts, (t + 1) * FL_TILE, nk, mk, kr);
+            tile_to_regs<HD>(vb, a.v_ts, (t + 1) * FL_TILE, nk, mv, vr);
         }
         bf16x8 kf[4][C::KCH];
 #pragma unroll
@@ -126,7 +153,7 @@ attn_fwd_flash_kernel(AttnArgs a) {
         // counts: the key mask exists only in a ragged last tile, the scale rides in the exp2 argument's FMA, exp2 is
         // the raw v_exp_f32 (a probability below 2^-126 is 0 either way) and O is rescaled only when some lane's
         // running maximum moved.
-        auto tile_body = [&](auto ragged_tag) {
+        {
         constexpr bool RAGGED = decltype(ragged_tag)::value;
         f32x4 st[FL_W][4];
 #pragma unroll
@@ -181,16 +208,17 @@ attn_fwd_flash_kernel(AttnArgs a) {
                 for (int w = 0; w < FL_W; ++w)
                     o[w][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt, pack_pair(st[w][2 * k2], st[w][2 * k2 + 1]), o[w][dt], 0, 0, 0);
             }
-        };
-        if ((t + 1) * FL_TILE > nk) tile_body(std::true_type{});   // one wave-uniform branch per tile
-        else tile_body(std::false_type{});
+        }
         if (t + 1 < ntiles) {
             char* nks = smem + ((t + 1) & 1) * 2 * F::TILE_BYTES;
-            regs_to_tile<HD>(nks, (t + 1) * FL_TILE, nk, tid, kr);
-            regs_to_tile<HD>(nks + F::TILE_BYTES, (t + 1) * FL_TILE, nk, tid, vr);
+            regs_to_tile<HD>(nks, (t + 1) * FL_TILE, nk, mk, kr);
+            regs_to_tile<HD>(nks + F::TILE_BYTES, (t + 1) * FL_TILE, nk, mv, vr);
         }
         __syncthreads();
-    }
+    };
+    const int nfull = nk / FL_TILE;     // tiles without a masked key
+    for (int t = 0; t < nfull; ++t) iteration(t, std::false_type{});
+    if (nfull < ntiles) iteration(nfull, std::true_type{});
 #pragma unroll
     for (int w = 0; w < FL_W; ++w) {
         const int q = q0 + 16 * w + fr;
@@ -257,17 +285,19 @@ attn_bwd_dq_flash_kernel(AttnArgs a) {
     }
     const int ntiles = (nk + FL_TILE - 1) / FL_TILE;
     bf16x8 kr[F::PASSES], vr[F::PASSES];
-    tile_to_regs<HD>(kb, a.k_ts, 0, nk, tid, kr);
-    tile_to_regs<HD>(vb, a.v_ts, 0, nk, tid, vr);
-    regs_to_tile<HD>(smem, 0, nk, tid, kr);
-    regs_to_tile<HD>(smem + F::TILE_BYTES, 0, nk, tid, vr);
+    const TileMap<HD> mk(tid);
+    const TileMap<HD>& mv = mk;
+    tile_to_regs<HD>(kb, a.k_ts, 0, nk, mk, kr);
+    tile_to_regs<HD>(vb, a.v_ts, 0, nk, mv, vr);
+    regs_to_tile<HD>(smem, 0, nk, mk, kr);
+    regs_to_tile<HD>(smem + F::TILE_BYTES, 0, nk, mv, vr);
     __syncthreads();
     for (int t = 0; t < ntiles; ++t) {
         const char* ks = smem + (t & 1) * 2 * F::TILE_BYTES;
         const char* vs = ks + F::TILE_BYTES;
         if (t + 1 < ntiles) {
-            tile_to_regs<HD>(kb, a.k_ts, (t + 1) * FL_TILE, nk, tid, kr);
-            tile_to_regs<HD>(vb, a.v_ts, (t + 1) * FL_TILE, nk, tid, vr);
+            tile_to_regs<HD>(kb, a.k_ts, (t + 1) * FL_TILE, nk, mk, kr);
+            tile_to_regs<HD>(vb, a.v_ts, (t + 1) * FL_TILE, nk, mv, vr);
         }
         bf16x8 kf[4][C::KCH], vf[4][C::KCH];
 #pragma unroll
@@ -310,8 +340,8 @@ attn_bwd_dq_flash_kernel(AttnArgs a) {
         else tile_body(std::false_type{});
         if (t + 1 < ntiles) {
             char* nks = smem + ((t + 1) & 1) * 2 * F::TILE_BYTES;
-            regs_to_tile<HD>(nks, (t + 1) * FL_TILE, nk, tid, kr);
-            regs_to_tile<HD>(nks + F::TILE_BYTES, (t + 1) * FL_TILE, nk, tid, vr);
+            regs_to_tile<HD>(nks, (t + 1) * FL_TILE, nk, mk, kr);
+            regs_to_tile<HD>(nks + F::TILE_BYTES, (t + 1) * FL_TILE, nk, mv, vr);
         }
         __syncthreads();
     }
@@ -368,6 +398,8 @@ attn_bwd_dkv_flash_kernel(AttnArgs a) {
     }
     const int ntiles = (nq + FL_TILE - 1) / FL_TILE;
     bf16x8 qr[F::PASSES], dor[F::PASSES];
+    const TileMap<HD> mq(tid);
+    const TileMap<HD>& mdo = mq;
     float statr = 0.f;
     auto load_stats = [&](int t) {
         if (tid < 2 * FL_TILE) {
@@ -379,11 +411,11 @@ attn_bwd_dkv_flash_kernel(AttnArgs a) {
     auto store_stats = [&](char* stage) {
         if (tid < 2 * FL_TILE) ((float*)(stage + 2 * F::TILE_BYTES))[tid] = statr;
     };
-    tile_to_regs<HD>(qb, a.q_ts, 0, nq, tid, qr);
-    tile_to_regs<HD>(dob, a.o_ts, 0, nq, tid, dor);
+    tile_to_regs<HD>(qb, a.q_ts, 0, nq, mq, qr);
+    tile_to_regs<HD>(dob, a.o_ts, 0, nq, mdo, dor);
     load_stats(0);
-    regs_to_tile<HD>(smem, 0, nq, tid, qr);
-    regs_to_tile<HD>(smem + F::TILE_BYTES, 0, nq, tid, dor);
+    regs_to_tile<HD>(smem, 0, nq, mq, qr);
+    regs_to_tile<HD>(smem + F::TILE_BYTES, 0, nq, mdo, dor);
     store_stats(smem);
     __syncthreads();
     for (int t = 0; t < ntiles; ++t) {
@@ -392,8 +424,8 @@ attn_bwd_dkv_flash_kernel(AttnArgs a) {
         const float* lse_s = (const float*)(qs + 2 * F::TILE_BYTES);
         const float* del_s = lse_s + FL_TILE;
         if (t + 1 < ntiles) {
-            tile_to_regs<HD>(qb, a.q_ts, (t + 1) * FL_TILE, nq, tid, qr);
-            tile_to_regs<HD>(dob, a.o_ts, (t + 1) * FL_TILE, nq, tid, dor);
+            tile_to_regs<HD>(qb, a.q_ts, (t + 1) * FL_TILE, nq, mq, qr);
+            tile_to_regs<HD>(dob, a.o_ts, (t + 1) * FL_TILE, nq, mdo, dor);
             load_stats(t + 1);
         }
         auto tile_body = [&](auto ragged_tag) {   // VALU-bound: see the forward kernel
@@ -439,8 +471,8 @@ attn_bwd_dkv_flash_kernel(AttnArgs a) {
         else tile_body(std::false_type{});
         if (t + 1 < ntiles) {
             char* nst = smem + ((t + 1) & 1) * STAGE_BYTES;
-            regs_to_tile<HD>(nst, (t + 1) * FL_TILE, nq, tid, qr);
-            regs_to_tile<HD>(nst + F::TILE_BYTES, (t + 1) * FL_TILE, nq, tid, dor);
+            regs_to_tile<HD>(nst, (t + 1) * FL_TILE, nq, mq, qr);
+            regs_to_tile<HD>(nst + F::TILE_BYTES, (t + 1) * FL_TILE, nq, mdo, dor);
             store_stats(nst);
         }
         __syncthreads();
@@ -488,7 +520,14 @@ static int launch_flash_bwd(const AttnArgs& a, hipStream_t s) {
 #endif
 
 #if FLASH_PART != 2
+// the staging code addresses a tile as a 64-bit base + 32-bit byte offsets: 64 rows x token stride x 2 B must fit
+static inline bool flash_strides_ok(const AttnArgs& a) {
+    constexpr int64_t LIM = (int64_t)1 << 24;
+    return a.q_ts < LIM && a.k_ts < LIM && a.v_ts < LIM && a.o_ts < LIM;
+}
+
 int attention_fwd_flash(const AttnArgs& a, hipStream_t s) {
+    if (!flash_strides_ok(a)) return VITED_ERR_UNSUPPORTED;
     if (a.head_dim == 32) return launch_flash_fwd<32>(a, s);
     if (a.head_dim == 64) return launch_flash_fwd<64>(a, s);
     return VITED_ERR_UNSUPPORTED;
@@ -498,6 +537,8 @@ int attention_fwd_flash(const AttnArgs& a, hipStream_t s) {
 
 #if FLASH_PART != 1
 int attention_bwd_flash(const AttnArgs& a, hipStream_t s) {
+    if (a.q_ts >= ((int64_t)1 << 24) || a.k_ts >= ((int64_t)1 << 24) || a.v_ts >= ((int64_t)1 << 24) || a.o_ts >= ((int64_t)1 << 24))
+        return VITED_ERR_UNSUPPORTED;
     if (a.head_dim == 32) return launch_flash_bwd<32>(a, s);
     if (a.head_dim == 64) return launch_flash_bwd<64>(a, s);
     return VITED_ERR_UNSUPPORTED;
