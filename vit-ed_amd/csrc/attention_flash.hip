@@ -292,7 +292,7 @@ attn_bwd_dq_flash_kernel(AttnArgs a) {
     regs_to_tile<HD>(smem, 0, nk, mk, kr);
     regs_to_tile<HD>(smem + F::TILE_BYTES, 0, nk, mv, vr);
     __syncthreads();
-    for (int t = 0; t < ntiles; ++t) {
+    auto iteration = [&](int t, auto ragged_tag) {   // the ragged last tile is peeled out of the loop (see the forward kernel)
         const char* ks = smem + (t & 1) * 2 * F::TILE_BYTES;
         const char* vs = ks + F::TILE_BYTES;
         if (t + 1 < ntiles) {
@@ -305,7 +305,7 @@ attn_bwd_dq_flash_kernel(AttnArgs a) {
             lds_row_frags<HD>(ks, kt, fr, g, kf[kt]);
             lds_row_frags<HD>(vs, kt, fr, g, vf[kt]);
         }
-        auto tile_body = [&](auto ragged_tag) {   // VALU-bound like the forward loop: same instruction diet
+        {   // VALU-bound like the forward loop: same instruction diet
         constexpr bool RAGGED = decltype(ragged_tag)::value;
         f32x4 ds[FL_W][4];
 #pragma unroll
@@ -335,16 +335,17 @@ attn_bwd_dq_flash_kernel(AttnArgs a) {
                 for (int w = 0; w < FL_W; ++w)
                     dq[w][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt_, pack_pair(ds[w][2 * k2], ds[w][2 * k2 + 1]), dq[w][dt], 0, 0, 0);
             }
-        };
-        if ((t + 1) * FL_TILE > nk) tile_body(std::true_type{});
-        else tile_body(std::false_type{});
+        }
         if (t + 1 < ntiles) {
             char* nks = smem + ((t + 1) & 1) * 2 * F::TILE_BYTES;
             regs_to_tile<HD>(nks, (t + 1) * FL_TILE, nk, mk, kr);
             regs_to_tile<HD>(nks + F::TILE_BYTES, (t + 1) * FL_TILE, nk, mv, vr);
         }
         __syncthreads();
-    }
+    };
+    const int nfull = nk / FL_TILE;
+    for (int t = 0; t < nfull; ++t) iteration(t, std::false_type{});
+    if (nfull < ntiles) iteration(nfull, std::true_type{});
 #pragma unroll
     for (int w = 0; w < FL_W; ++w) {
         const int q = q0 + 16 * w + fr;
@@ -418,7 +419,7 @@ attn_bwd_dkv_flash_kernel(AttnArgs a) {
     regs_to_tile<HD>(smem + F::TILE_BYTES, 0, nq, mdo, dor);
     store_stats(smem);
     __syncthreads();
-    for (int t = 0; t < ntiles; ++t) {
+    auto iteration = [&](int t, auto ragged_tag) {   // the ragged last tile is peeled out of the loop (see the forward kernel)
         const char* qs = smem + (t & 1) * STAGE_BYTES;
         const char* dos = qs + F::TILE_BYTES;
         const float* lse_s = (const float*)(qs + 2 * F::TILE_BYTES);
@@ -428,7 +429,7 @@ attn_bwd_dkv_flash_kernel(AttnArgs a) {
             tile_to_regs<HD>(dob, a.o_ts, (t + 1) * FL_TILE, nq, mdo, dor);
             load_stats(t + 1);
         }
-        auto tile_body = [&](auto ragged_tag) {   // VALU-bound: see the forward kernel
+        {   // VALU-bound: see the forward kernel
         constexpr bool RAGGED = decltype(ragged_tag)::value;
         f32x4 pr[FL_W][4], ds[FL_W][4];
 #pragma unroll
@@ -466,9 +467,7 @@ attn_bwd_dkv_flash_kernel(AttnArgs a) {
                     dk[w][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt_, pack_pair(ds[w][2 * q2], ds[w][2 * q2 + 1]), dk[w][dt], 0, 0, 0);
                 }
             }
-        };
-        if ((t + 1) * FL_TILE > nq) tile_body(std::true_type{});
-        else tile_body(std::false_type{});
+        }
         if (t + 1 < ntiles) {
             char* nst = smem + ((t + 1) & 1) * STAGE_BYTES;
             regs_to_tile<HD>(nst, (t + 1) * FL_TILE, nq, mq, qr);
@@ -476,7 +475,10 @@ attn_bwd_dkv_flash_kernel(AttnArgs a) {
             store_stats(nst);
         }
         __syncthreads();
-    }
+    };
+    const int nfull = nq / FL_TILE;
+    for (int t = 0; t < nfull; ++t) iteration(t, std::false_type{});
+    if (nfull < ntiles) iteration(nfull, std::true_type{});
 #pragma unroll
     for (int w = 0; w < FL_W; ++w) {
         const int key = k0 + 16 * w + fr;
