@@ -164,15 +164,23 @@ mlp_fwd_fused_kernel(MlpArgs a) {
         outT[i][0] = f32x4{0.f, 0.f, 0.f, 0.f};
         outT[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    // Lane parts of the fragment addresses inside a piece.  fc1's hidden rows are taken in a PERMUTED order inside every group of
+    // 32: tile 2 s holds hidden 32 s + 8 (i >> 2) + (i & 3) in its row i, tile 2 s + 1 the same + 4.  A lane's accumulators of the
+    // tile pair are then 8 CONSECUTIVE hidden units (32 s + 8 fq .. + 7) = the k order of one 32-deep step of fc2, so the packed
+    // accumulators are fc2's B operand AND the matching W2 fragment is 16 contiguous bytes of a W2 row: one ds_read_b128 (with
+    // fc1's rows in natural order it was two 8-byte halves 32 bytes apart, which hipcc fused across fragments into
+    // ds_read2st64_b64 + 4 v_mov per fragment: 275 moves per 128-wide chunk).
     const int sw = (fr >> 1) & 7;
-    // lane parts of the fragment addresses inside a piece (row fr of a 16-row group, see the file header)
-    const int a1_k0 = fr * 128 + ((fq ^ sw) << 4);            // W1 fragment, k-step 0 of the piece (chunk fq)
-    const int a1_k1 = fr * 128 + (((4 + fq) ^ sw) << 4);      //              k-step 1 (chunk 4 + fq)
-    const int half8 = (fq & 1) * 8, cq = fq >> 1;
-    const int a2_lo0 = fr * 128 + ((cq ^ sw) << 4) + half8;             // W2 fragment halves, k-step 0: chunks cq, cq + 2
-    const int a2_hi0 = fr * 128 + (((cq + 2) ^ sw) << 4) + half8;
-    const int a2_lo1 = fr * 128 + (((4 + cq) ^ sw) << 4) + half8;       //                       k-step 1: chunks 4 + cq, 6 + cq
-    const int a2_hi1 = fr * 128 + (((6 + cq) ^ sw) << 4) + half8;
+    // k-step 1 of a piece is chunk 4 + fq instead of fq: the same address with bit 6 flipped (the swizzle is an XOR below bit 7), so only
+    // the k-step-0 addresses are kept in registers (the kernel sits at the 512-register limit)
+    const int a2_k0 = fr * 128 + ((fq ^ sw) << 4);            // W2 fragment (row fr of a 16-row group), k-step 0 of the piece (chunk fq)
+    int a1_k0[2];                                             // W1 fragment of an even / odd tile: permuted row
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+        const int row = 8 * (fr >> 2) + 4 * par + (fr & 3);
+        const int swr = (row >> 1) & 7;                       // the 32-row group offset is a multiple of 16: it does not enter the swizzle
+        a1_k0[par] = row * 128 + ((fq ^ swr) << 4);
+    }
 
     for (int c = 0; c < 12; ++c) {
         f32x4 zT[8][2];
@@ -195,7 +203,7 @@ mlp_fwd_fused_kernel(MlpArgs a) {
             // latency in front of every pair of MFMAs: 6x slower)
             bf16x8 wa[8], wb[8];
 #define MF_LOAD1(BUF, G) _Pragma("unroll") for (int ht = 0; ht < 8; ++ht) \
-                BUF[ht] = *(const bf16x8*)(sl + ((G) >> 1) * MF_PIECE + (((G) & 1) ? a1_k1 : a1_k0) + ht * 2048)
+                BUF[ht] = *(const bf16x8*)(sl + ((G) >> 1) * MF_PIECE + (a1_k0[ht & 1] ^ (((G) & 1) << 6)) + (ht >> 1) * 4096)
 #ifdef MF_ABL_NOMFMA
 #define MF_MMA1(BUF, G) _Pragma("unroll") for (int ht = 0; ht < 8; ++ht) { asm volatile("" :: "v"(BUF[ht]), "v"(hfrag[0][4 * idx + (G)]), "v"(hfrag[1][4 * idx + (G)])); }
 #else
@@ -221,11 +229,12 @@ mlp_fwd_fused_kernel(MlpArgs a) {
 #undef MF_MMA1
         }
         // ---- bias, GELU and its derivative on the accumulators; pack u^T as the B operand of the second product --------
-        // lane (fr, fq) holds hidden 16 ht + 4 fq + e (e = 0..3) of tokens fr, 16 + fr
+        // lane (fr, fq) holds hidden 32 (ht >> 1) + 8 fq + 4 (ht & 1) + e (e = 0..3) of tokens fr, 16 + fr (permuted rows, see above)
         bf16x8 ufrag[4][2];
 #pragma unroll
         for (int ht = 0; ht < 8; ++ht) {
-            const f32x4 bb = *(const f32x4*)(b1s + c * 128 + ht * 16 + 4 * fq);
+            const int hcol = 32 * (ht >> 1) + 8 * fq + 4 * (ht & 1);      // this lane's first hidden unit of the tile, inside the chunk
+            const f32x4 bb = *(const f32x4*)(b1s + c * 128 + hcol);
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
                 bf16x4 uu, gg;
@@ -243,8 +252,8 @@ mlp_fwd_fused_kernel(MlpArgs a) {
 #endif
                 }
                 // gd rows leave through the wave-private scratch as whole 256-byte row segments (staged right away: nothing is held)
-                if (SAVE) *(bf16x4*)(scr + (tt * 16 + fr) * MF_SCR_LD + (ht * 16 + 4 * fq) * 2) = gg;
-                // k order of fc2's 32-deep step s = ht / 2: element j < 4 <- tile 2 s, j >= 4 <- tile 2 s + 1 (same 4 fq + e)
+                if (SAVE) *(bf16x4*)(scr + (tt * 16 + fr) * MF_SCR_LD + hcol * 2) = gg;
+                // k order of fc2's 32-deep step s = ht / 2: element j < 4 <- tile 2 s, j >= 4 <- tile 2 s + 1: hidden 32 s + 8 fq + j
                 if (ht & 1) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) ufrag[ht >> 1][tt][4 + e] = uu[e];
@@ -265,7 +274,7 @@ mlp_fwd_fused_kernel(MlpArgs a) {
                         for (int tt = 0; tt < 2; ++tt) {
                             const bf16x8 uf = ufrag[ht >> 1][tt];
                             const bf16x4 val = (ht & 1) ? bf16x4{uf[4], uf[5], uf[6], uf[7]} : bf16x4{uf[0], uf[1], uf[2], uf[3]};
-                            *(bf16x4*)(scr + (tt * 16 + fr) * MF_SCR_LD + (ht * 16 + 4 * fq) * 2) = val;
+                            *(bf16x4*)(scr + (tt * 16 + fr) * MF_SCR_LD + (32 * (ht >> 1) + 8 * fq + 4 * (ht & 1)) * 2) = val;
                         }
                 }
                 asm volatile("" ::: "memory");   // wave-private LDS, a wave's DS operations execute in order: compiler fence only
@@ -291,10 +300,8 @@ mlp_fwd_fused_kernel(MlpArgs a) {
             }
             const char* sl = smem + (idx % 3) * MF_SUPER;
             bf16x8 wa[8], wb[8];
-#define MF_LOAD2(BUF, G) _Pragma("unroll") for (int nt = 0; nt < 8; ++nt) { \
-                const bf16x4 lo = *(const bf16x4*)(sl + ((G) >> 1) * MF_PIECE + (((G) & 1) ? a2_lo1 : a2_lo0) + nt * 2048); \
-                const bf16x4 hi = *(const bf16x4*)(sl + ((G) >> 1) * MF_PIECE + (((G) & 1) ? a2_hi1 : a2_hi0) + nt * 2048); \
-                BUF[nt] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]}; }
+#define MF_LOAD2(BUF, G) _Pragma("unroll") for (int nt = 0; nt < 8; ++nt) \
+                BUF[nt] = *(const bf16x8*)(sl + ((G) >> 1) * MF_PIECE + (a2_k0 ^ (((G) & 1) << 6)) + nt * 2048)
 #ifdef MF_ABL_NOMFMA
 #define MF_MMA2(BUF, G) _Pragma("unroll") for (int nt = 0; nt < 8; ++nt) { asm volatile("" :: "v"(BUF[nt]), "v"(ufrag[G][0]), "v"(ufrag[G][1])); }
 #else
