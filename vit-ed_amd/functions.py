@@ -221,8 +221,9 @@ def _fused_mlp_rows(rt, x, w1, grad):
     """How many leading rows the fused MLP kernel (vited_mlp_fwd) takes: it runs one 128-row workgroup per CU, so a last
     round that fills less than a quarter of the chip is left to the unfused kernels (66,560 rows = 520 tiles = 2 rounds + 8
     tiles: the 8 tiles would cost a third round).  0 = do not use it.  Measured (profiles/mlp_probe.py, M = 65,536): it beats
-    LayerNorm + fc1/GELU + fc2/residual when nothing is saved for backward (312 vs 347 us) and loses when the backward's
-    operands must be written (379 us), so it serves the no-grad paths (evaluation, similarity-matrix inference)."""
+    LayerNorm + fc1/GELU + fc2/residual when nothing is saved for backward (269 vs 344 us) and loses when the backward's
+    operands must be written (376 us; in the training step: +0.9 ms), so it serves the no-grad paths (evaluation,
+    similarity-matrix inference)."""
     if grad or rt.exact or not rt.fused_mlp or x.shape[1] != 384 or tuple(w1.shape) != (1536, 384) or x.stride(0) != 384:
         return 0
     tiles = x.shape[0] // FUSED_MLP_TILE
