@@ -48,7 +48,9 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
 // TN_STAGES == 3 build of round 1 measured exactly that drain, not the ring).  The caller counts vmcnt itself.
 __device__ __forceinline__ void glds16_asm(const void* g, void* l) {
     unsigned keep;
-    const unsigned dst = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)l;
+    // low 32 bits of the flat address of an LDS object = its LDS byte offset (the aperture sits in the high half); the proper
+    // generic -> local cast costs a null check per call (s_cmp_lg_u64 + s_cselect + the aperture load: 5 scalar instructions per piece)
+    const unsigned dst = (unsigned)(uintptr_t)l;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(g), "s"(__builtin_amdgcn_readfirstlane(dst)) : "memory");
 }
@@ -529,9 +531,7 @@ gemm_tn_mfma_kernel(const bf16* __restrict__ dY, int64_t lddy, const bf16* __res
 // three stages (96 KB) in flight per CU across the barrier - counted vmcnt, raw s_barrier, LDS-DMA from inline asm.
 // Taken when K is a multiple of 384 (every dW of the embed-384 models: qkv / kv / proj / fc1 / fc2).
 // ================================================================================================
-#ifndef TW_STAGES
-#define TW_STAGES 4
-#endif
+#define TW_STAGES 4   // a power of two: slot = stage & 3
 #define TW_PANEL_BYTES (32 * 256)
 #define TW_STAGE_BYTES (4 * TW_PANEL_BYTES)
 #define TW_PER 4   // LDS-DMA instructions per stage per wave
@@ -607,9 +607,10 @@ gemm_tn_wide_kernel(const bf16* __restrict__ dY, int64_t lddy, const bf16* __res
 #pragma unroll
     for (int i = 0; i < 4; ++i) p0[i] = pbase + (mb + rbase + i * 4 + rsub) * ld + coff[i];
     const int64_t stage_stride = 32 * ld;
+    const int rows_here = (int)(me - mb);            // rows of this split: 32-bit scalar arithmetic from here on
     auto issue = [&](int stage_idx) {   // stage_idx < nsteps
-        char* dst = smem + (stage_idx % TW_STAGES) * TW_STAGE_BYTES;
-        if (mb + (int64_t)(stage_idx + 1) * 32 <= me) {   // a real (scalar) branch: each arm issues its own DMA
+        char* dst = smem + (stage_idx & (TW_STAGES - 1)) * TW_STAGE_BYTES;
+        if ((stage_idx + 1) * 32 <= rows_here) {   // a real (scalar) branch: each arm issues its own DMA
             const int64_t adv = (int64_t)stage_idx * stage_stride;    // wave-uniform
             const bf16* src[4];
 #pragma unroll
@@ -619,9 +620,9 @@ gemm_tn_wide_kernel(const bf16* __restrict__ dY, int64_t lddy, const bf16* __res
             const bf16* src[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                int64_t gm = mb + (int64_t)stage_idx * 32 + rbase + i * 4 + rsub;
-                gm = gm < me ? gm : me - 1;          // clamped rows are zeroed in LDS after landing
-                src[i] = pbase + gm * ld + coff[i];
+                int r = stage_idx * 32 + rbase + i * 4 + rsub;
+                r = r < rows_here ? r : rows_here - 1;          // clamped rows are zeroed in LDS after landing
+                src[i] = pbase + (mb + r) * ld + coff[i];
             }
             tw_stage_issue(src, dst, panel, rbase);
         }
@@ -633,12 +634,12 @@ gemm_tn_wide_kernel(const bf16* __restrict__ dY, int64_t lddy, const bf16* __res
         else if (later >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * TW_PER) : "memory");
         else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TW_PER) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (mb + (int64_t)(idx + 1) * 32 > me) {   // ragged last stage: zero the rows this lane's DMA clamped
-            char* st = smem + (idx % TW_STAGES) * TW_STAGE_BYTES;
+        if ((idx + 1) * 32 > rows_here) {   // ragged last stage: zero the rows this lane's DMA clamped
+            char* st = smem + (idx & (TW_STAGES - 1)) * TW_STAGE_BYTES;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int r = rbase + i * 4 + rsub;
-                if (mb + (int64_t)idx * 32 + r >= me) *(f32x4*)(st + panel * TW_PANEL_BYTES + r * 256 + cp * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (idx * 32 + r >= rows_here) *(f32x4*)(st + panel * TW_PANEL_BYTES + r * 256 + cp * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
     };
@@ -685,7 +686,7 @@ gemm_tn_wide_kernel(const bf16* __restrict__ dY, int64_t lddy, const bf16* __res
         return;
 #endif
 #ifndef TW_DBG_NO_READS
-        if (t + 1 < nsteps) tw_read_frags(nxt, smem + ((t + 1) % TW_STAGES) * TW_STAGE_BYTES, ya_lo, ya_hi, xb_lo, xb_hi);
+        if (t + 1 < nsteps) tw_read_frags(nxt, smem + ((t + 1) & (TW_STAGES - 1)) * TW_STAGE_BYTES, ya_lo, ya_hi, xb_lo, xb_hi);
 #endif
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -726,11 +727,11 @@ gemm_tn_wide_kernel(const bf16* __restrict__ dY, int64_t lddy, const bf16* __res
             else if (later == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * TW_PER) : "memory");
             else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TW_PER) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (mb + 32 > me) {
+            if (32 > rows_here) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int r = rbase + i * 4 + rsub;
-                    if (mb + r >= me) *(f32x4*)(smem + panel * TW_PANEL_BYTES + r * 256 + cp * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (r >= rows_here) *(f32x4*)(smem + panel * TW_PANEL_BYTES + r * 256 + cp * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
