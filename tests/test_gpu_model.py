@@ -176,6 +176,35 @@ def test_against_oracle_random_init(vited, gpu, dtype, depth):
         assert total(gh) < 2e-2 and total(gh) <= 1.5 * total(gac) + 1e-3, (total(gh), total(gac))
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('embed_dim,heads,batch', [(768, 12, 80), (192, 6, 16), (512, 8, 16)])
+def test_other_widths_against_oracle(vited, gpu, dtype, embed_dim, heads, batch):
+    """Widths other than the shipped 384 (the factory forwards MODEL.PJS.EMBED_DIM / NUM_HEADS, models/build.py:19-32): 768 with
+    head dim 64 (two 384-wide k panels in the wide weight-gradient tile at batch 80 = 5,120+ rows, hidden 3072), 192 and 512
+    (K not a multiple of 384: the 128 x 128 dW tile; 512 / 8 = head dim 64).  Random init, 1 + 1 blocks, against the fp32 oracle."""
+    torch.manual_seed(1)
+    s = vo.ViTEDShape(embed_dim=embed_dim, num_heads=heads, depth=1, c_depth=1)
+    oracle = vo.OracleViTED(s)
+    model = _hip_model(vited, s, gpu, dtype)
+    model.load_state_dict(oracle.state_dict())
+    x = torch.randn(batch, 2, 3, 64, 64).clamp(-1, 1)
+    y = (torch.rand(batch, 4) > 0.75).float()
+    out = oracle(x)
+    torch.nn.functional.binary_cross_entropy_with_logits(out.float(), y).backward()
+    lh = model(x.to(gpu))
+    torch.nn.functional.binary_cross_entropy_with_logits(lh, y.to(gpu)).backward()
+    exact = dtype == torch.float32
+    torch.testing.assert_close(lh.detach().cpu(), out.detach().float(), **(dict(rtol=1e-3, atol=1e-5) if exact else dict(rtol=3e-2, atol=3e-2)))
+    num = den = 0.0
+    for (n, p), q in zip(model.named_parameters(), oracle.parameters()):
+        g, r = p.grad.cpu().double(), q.grad.double()
+        err = float((g - r).norm() / (r.norm() + 1e-12))
+        assert err < (1e-3 if exact else 6e-2), f'{n}: relative gradient error {err:.3e}'
+        num += float((g - r).norm() ** 2)
+        den += float(r.norm() ** 2)
+    assert (num / den) ** 0.5 < (1e-4 if exact else 2.5e-2)
+
+
 @pytest.mark.parametrize('case', ['rand8', 'A_full'])
 def test_bf16_error_growth_per_block(vited, gpu, case):
     """Where bf16 error enters, block by block (taps in functions.py): the output of every encoder / decoder block in
