@@ -39,6 +39,9 @@ CASES = {
     'H_full': (vo.SHAPE_H, 1, False),
     # config H's token counts (1024 / 1025: the flash attention forward AND backward kernels) at 1 + 1 blocks, with backward
     'H_1x1_512': (vo.ViTEDShape(img_size=512, patch_size=16, num_classes=1, num_heads=6, depth=1, c_depth=1), 2, True),
+    # ... and at 4 + 4 blocks with backward: gradient flow through stacked flash-attention blocks, d(features) accumulated over
+    # four cross-attention blocks, the cls-only last decoder block behind three full ones
+    'H_4x4_512': (vo.ViTEDShape(img_size=512, patch_size=16, num_classes=1, num_heads=6, depth=4, c_depth=4), 2, True),
 }
 
 

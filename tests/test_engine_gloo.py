@@ -167,7 +167,7 @@ def test_flat_scaler_survives_the_reference_loop_order():
 
 def test_train_step_accumulation_and_lr_schedule_cpu():
     """TrainStep(accumulation_steps=2, lr_scheduler=...) == the reference loop's arithmetic: loss / 2 per micro-step,
-    one update per two calls, lr_scheduler.step_update(num_updates) after each update (misc/engine.py:212-231)."""
+    one update per two calls, lr_scheduler.step_update(updates done before this one) after each update (misc/engine.py:212-231)."""
     import vited_amd
     from vited_amd import engine
     torch.manual_seed(0)
@@ -197,10 +197,15 @@ def test_train_step_accumulation_and_lr_schedule_cpu():
             torch.nn.utils.clip_grad_norm_(b.parameters(), 5.0)
             ob.step()
             ob.zero_grad()
-            sb.step_update(it // 2 + 1)
-    assert sa.seen == [1, 2, 3] and step.num_updates == 3
+            sb.step_update(it // 2)               # misc/engine.py:228: (epoch * num_steps + idx) // ACCUMULATION_STEPS = 0, 1, 2
+    assert sa.seen == [0, 1, 2] and step.num_updates == 3
     for (n, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
         torch.testing.assert_close(p, q, rtol=1e-4, atol=5e-5, msg=lambda m: f'{n}: {m}')
+    # a resumed run continues the schedule: start_update = epoch * num_steps // accumulation_steps
+    resumed = engine.TrainStep(a, oa, clip_grad=5.0, amp=False, accumulation_steps=2, lr_scheduler=sa, start_update=40)
+    for it in range(2):
+        resumed.step(*_data(4))
+    assert sa.seen[-1] == 40 and resumed.num_updates == 41
 
 
 def test_scaler_call_shape_matches_reference():

@@ -314,3 +314,176 @@ def test_hip_model_under_torch_ddp_wrap_matches_single_process(vited, gpu, tmp_p
     for k, v in m.state_dict().items():
         # DDP averages the two shard gradients: the full-batch gradient up to fp32 summation order (AdamW amplifies that on ~0 gradients)
         torch.testing.assert_close(got[k], v.cpu(), rtol=1e-3, atol=2e-4, msg=lambda msg: f'{k}: {msg}')
+
+
+# ---------------------------------------------------------------------------------------------
+# similarity-matrix inference sharded over two ranks WITH the HIP model and the pair cache (BASELINE config 5): rank 1's row
+# block starts at r0 > 0, so its image-2 token cache starts at image r0 and is indexed j - r0 (engine.pairwise_similarity)
+# ---------------------------------------------------------------------------------------------
+_SIM_SHAPE = dict(img_size=256, patch_size=16, num_classes=1, num_heads=6, depth=1, c_depth=2)
+_SIM_N = 11
+
+
+def _sim_rank(rank, world, port, out_dir, state_path):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+    import vited_amd as V
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0')
+    dist.init_process_group('gloo', init_method='env://', world_size=world, rank=rank)
+    dev = torch.device('cuda:0')
+    torch.cuda.set_device(dev)
+    s = vo.ViTEDShape(**_SIM_SHAPE)
+    m = V.VisionTransformerCustom(img_size=s.img_size, patch_size=s.patch_size, num_classes=s.num_classes, embed_dim=s.embed_dim,
+                                  depth=s.depth, c_depth=s.c_depth, num_heads=s.num_heads).to(dev).eval()
+    m.load_state_dict(torch.load(state_path, weights_only=True))
+    imgs = torch.randn(_SIM_N, 3, s.img_size, s.img_size, generator=torch.Generator().manual_seed(17)).clamp(-1, 1).to(dev)
+    bounds = V.engine.shard_rows_by_pair_count(_SIM_N, world)
+    res = {'bounds': bounds}
+    for name, dtype in (('f32', torch.float32), ('bf16', torch.bfloat16)):
+        m.compute_dtype = dtype
+        assert m.supports_pair_cache
+        sim = V.engine.pairwise_similarity(m, imgs, rank=rank, world=world, block=3, pair_batch=16, amp=dtype == torch.bfloat16)
+        res[name] = sim.cpu()
+    torch.save(res, os.path.join(out_dir, f'sim_{rank}.pt'))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_pair_cached_similarity_matches_the_oracle(vited, gpu, tmp_path):
+    s = vo.ViTEDShape(**_SIM_SHAPE)
+    torch.manual_seed(31)
+    oracle = vo.OracleViTED(s).eval()
+    state = str(tmp_path / 'state.pt')
+    torch.save(oracle.state_dict(), state)
+    mp.spawn(_sim_rank, args=(2, 29300 + os.getpid() % 150, str(tmp_path), state), nprocs=2, join=True)
+    r0, r1 = (torch.load(str(tmp_path / f'sim_{r}.pt'), weights_only=True) for r in (0, 1))
+    bounds = r0['bounds']
+    assert 0 < bounds[1] < _SIM_N, f'rank 1 must own a non-empty row block that does not start at image 0: {bounds}'
+    imgs = torch.randn(_SIM_N, 3, s.img_size, s.img_size, generator=torch.Generator().manual_seed(17)).clamp(-1, 1)
+    i, j = torch.triu_indices(_SIM_N, _SIM_N)
+    with torch.no_grad():
+        ref = oracle(torch.stack([imgs[i], imgs[j]], dim=1)).reshape(-1)       # the naive one-shot pairs (hisfrag.py:226-229)
+    mine1 = i >= bounds[1]                                                      # pairs computed BY RANK 1 (rows r0..n)
+    assert int(mine1.sum()) > 0 and int((~mine1).sum()) > 0
+    for name, tol in (('f32', dict(rtol=2e-3, atol=2e-3)), ('bf16', dict(rtol=3e-2, atol=3e-2))):
+        assert torch.equal(r0[name], r1[name]), 'both ranks must rebuild the same matrix from the all-gather'
+        sim = r0[name]
+        assert torch.equal(sim, sim.t())
+        torch.testing.assert_close(sim[i, j][mine1].float(), ref[mine1], msg=lambda m: f'{name}, rank 1 block: {m}', **tol)
+        torch.testing.assert_close(sim[i, j][~mine1].float(), ref[~mine1], msg=lambda m: f'{name}, rank 0 block: {m}', **tol)
+
+
+# ---------------------------------------------------------------------------------------------
+# the reference's own loop around engine.build_optimizer()'s default optimizer
+# ---------------------------------------------------------------------------------------------
+def _cfg_a(vited, **train):
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = vited.config_from_yaml(os.path.join(here, 'configs', 'puzzle', 'div2k_erosion7_4bin_patch8_64.yaml'))
+    return cfg
+
+
+def test_build_optimizer_default_under_the_reference_loop_keeps_bf16_shadows_fresh(vited, gpu):
+    """``engine.build_optimizer`` hands out ``FlatAdamW`` on a GPU model.  Driven the way the reference drives ANY optimizer
+    (misc/engine.py:208-231: autocast forward, ``loss_scaler(loss, optimizer, clip_grad, parameters)`` - which calls the plain
+    ``optimizer.step()`` - then ``optimizer.zero_grad()``) the update kernel raw-writes the fp32 parameters, so the bf16 weight
+    shadows the MFMA kernels read must follow: the losses must move like a torch.optim.AdamW run of the same loop, and an eval
+    forward after training must equal the forward of a freshly built model loaded from the checkpoint, bit for bit."""
+    s = vo.ViTEDShape(depth=1, c_depth=1)
+    cfg = _cfg_a(vited)
+    torch.manual_seed(41)
+    init = _hip_model(vited, s, gpu, None).state_dict()
+    runs = {}
+    for kind in ('flat_hip', 'torch'):
+        m = _hip_model(vited, s, gpu, None)
+        m.load_state_dict(init)
+        opt = vited.engine.build_optimizer(cfg, m, fused_hip=(kind == 'flat_hip'))
+        assert isinstance(opt, vited.optim.FlatAdamW) == (kind == 'flat_hip')
+        for g_ in opt.param_groups:
+            g_['lr'] = 1e-3
+        scaler = vited.engine.NativeScalerWithGradNormCount()        # no flat buffer: the reference's call shape
+        g = torch.Generator().manual_seed(13)
+        losses = []
+        opt.zero_grad()
+        for it in range(4):
+            x = torch.randn(8, 2, 3, 64, 64, generator=g).clamp(-1, 1).to(gpu)
+            y = (torch.rand(8, 4, generator=g) > 0.6).float().to(gpu)
+            with torch.autocast('cuda', dtype=torch.bfloat16):
+                loss = bce(m(x).float(), y)
+            scaler(loss, opt, clip_grad=5.0, parameters=m.parameters())
+            opt.zero_grad()
+            losses.append(float(loss))
+        runs[kind] = (m, losses)
+    m, losses = runs['flat_hip']
+    _, want_losses = runs['torch']
+    # with stale shadows every forward after the first would run on the initial weights: same-batch-free losses would not track
+    for a, b in zip(losses, want_losses):
+        assert abs(a - b) < 2e-2 * max(1.0, abs(b)), (losses, want_losses)
+    for (n, p), (_, q) in zip(m.named_parameters(), runs['torch'][0].named_parameters()):
+        torch.testing.assert_close(p, q, rtol=2e-2, atol=2e-3, msg=lambda msg: f'{n}: {msg}')
+    x = torch.randn(4, 2, 3, 64, 64, generator=torch.Generator().manual_seed(2)).clamp(-1, 1).to(gpu)
+    with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16):
+        after = m.eval()(x)
+        fresh = _hip_model(vited, s, gpu, None)
+        fresh.load_state_dict(m.state_dict())
+        want = fresh.eval()(x)
+    assert torch.equal(after, want), 'stale bf16 weight shadows: the forward did not see the updated parameters'
+    # ... and with an optimizer that was NOT given the model (shadows unknown to the kernel) the version bump makes the model recast
+    m2 = _hip_model(vited, s, gpu, None)
+    m2.load_state_dict(init)
+    opt2 = vited.optim.FlatAdamW(vited.engine.param_groups_no_decay_1d(m2), lr=1e-3, weight_decay=0.05)
+    x8 = torch.randn(8, 2, 3, 64, 64, generator=torch.Generator().manual_seed(3)).clamp(-1, 1).to(gpu)
+    y8 = (torch.rand(8, 4, generator=torch.Generator().manual_seed(4)) > 0.6).float().to(gpu)
+    for it in range(2):
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            bce(m2(x8).float(), y8).backward()
+        opt2.step()
+        opt2.zero_grad()
+    with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16):
+        fresh2 = _hip_model(vited, s, gpu, None)
+        fresh2.load_state_dict(m2.state_dict())
+        assert torch.equal(m2.eval()(x), fresh2.eval()(x))
+
+
+def test_flat_adamw_resume_before_bind_keeps_the_step_count(vited, gpu):
+    """The reference resumes as: build optimizer -> load_checkpoint (optimizer.load_state_dict) -> build the loop
+    (misc/utils.py:57-70).  ``FlatAdamW.load_state_dict`` BEFORE ``bind_flat`` / ``TrainStep`` must carry the AdamW step
+    count (bias correction) as well as the moments: the first resumed update equals torch.optim.AdamW's."""
+    torch.manual_seed(0)
+    shapes = [(384, 384), (384,), (4, 384)]
+    base = [torch.randn(sh, device=gpu) * 0.1 for sh in shapes]
+
+    def groups(ps):
+        return [{'params': [p for p in ps if p.ndim > 1]}, {'params': [p for p in ps if p.ndim <= 1], 'weight_decay': 0.0}]
+
+    kw = dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05)
+    ref = [torch.nn.Parameter(b.clone()) for b in base]
+    topt = torch.optim.AdamW(groups(ref), **kw)
+    gen = torch.Generator(device=gpu).manual_seed(5)
+    grads = [[torch.randn(sh, device=gpu, generator=gen) * 0.01 for sh in shapes] for _ in range(6)]
+    for it in range(5):
+        for p, g in zip(ref, grads[it]):
+            p.grad = g.clone()
+        topt.step()
+    ckpt = {'opt': topt.state_dict(), 'params': [p.detach().clone() for p in ref]}
+    # resume: fresh parameters + FlatAdamW, load BEFORE anything binds a flat buffer
+    mine = [torch.nn.Parameter(p.clone()) for p in ckpt['params']]
+    opt = vited.optim.FlatAdamW(groups(mine), **kw)
+    opt.load_state_dict(ckpt['opt'])
+    assert opt.num_updates == 5 and float(opt.state_dict()['state'][0]['step']) == 5.0      # unbound: the loaded step survives a re-save
+    flat = vited.engine.FlatGradients(mine)
+    opt.bind_flat(flat)
+    assert opt.num_updates == 5
+    for p, q, g in zip(mine, ref, grads[5]):
+        p.grad.copy_(g)
+        q.grad = g.clone()
+    topt.step()
+    opt.step_flat(None)
+    for i, (p, q) in enumerate(zip(mine, ref)):
+        torch.testing.assert_close(p, q, rtol=2e-6, atol=1e-6, msg=lambda m: f'param {i}: {m}')
+    assert opt.num_updates == 6
+    # load AFTER binding copies into the existing buffers (a captured update graph keeps reading them)
+    ptr = opt.exp_avg.data_ptr()
+    opt.load_state_dict(ckpt['opt'])
+    assert opt.exp_avg.data_ptr() == ptr and opt.num_updates == 5
+    torch.testing.assert_close(opt.state[mine[0]]['exp_avg'], ckpt['opt']['state'][0]['exp_avg'])

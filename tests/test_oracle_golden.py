@@ -9,7 +9,7 @@ import torch
 from oracle import vited_oracle as vo
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
-CASES = ['T', 'A_1x1', 'A_2x2', 'H_1x1_128', 'A_full']
+CASES = ['T', 'A_1x1', 'A_2x2', 'H_1x1_128', 'A_full', 'H_1x1_512', 'H_4x4_512']
 
 
 def _load(name):

@@ -32,15 +32,6 @@ extern "C" int vited_gemm(const void* A, int64_t lda, const void* B, int64_t ldb
     ep.row_offset = row_offset;
     ep.residual_bcast = residual_bcast;
     hipStream_t s = (hipStream_t)stream;
-    // VITED_NT=as opts the K = 384 Linears into the persistent activation-stationary kernel
-    // (gemm_nt_as.hip).  Measured on MI355X it ties the tile kernel (DESIGN.md section "GEMM"), so the
-    // tile kernel stays the default; the persistent one is kept as the base of the fused-block work.
-    static const char* nt_env = getenv("VITED_NT");
-    static const bool use_as = nt_env && !strcmp(nt_env, "as");
-    if (dtype == VITED_BF16 && b_layout == VITED_B_NK && use_as && gemm_nt_as_supported(A, lda, B, ldb, M, N, K, epilogue, ep)) {
-        g_last_gemm_path = 3;
-        return gemm_nt_as(A, lda, B, ldb, M, N, K, epilogue, ep, s);
-    }
     if (dtype == VITED_BF16 && b_layout == VITED_B_NK && gemm_nt_mfma_supported(A, lda, B, ldb, M, N, K, epilogue, ep)) {
         g_last_gemm_path = 2;
         return gemm_nt_mfma(A, lda, B, ldb, M, N, K, epilogue, ep, s);

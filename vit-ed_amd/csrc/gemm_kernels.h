@@ -23,9 +23,3 @@ int sum_rows_f32_single_pass(const float* in, int64_t in_ld, float* out, int64_t
                              int accumulate = 0);
 int sum_slabs_pair(const float* in_a, int64_t ld_a, float* out_a, int64_t width_a, const float* in_b, int64_t ld_b, float* out_b,
                    int64_t width_b, int64_t batch, hipStream_t s, int accumulate);
-
-// activation-stationary persistent NT kernel for K == 384 (gemm_nt_as.hip)
-bool gemm_nt_as_supported(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K, int epilogue,
-                          const EpiParams& ep);
-int gemm_nt_as(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K, int epilogue,
-               const EpiParams& ep, hipStream_t s);

@@ -1,19 +1,26 @@
 // bf16 MFMA GEMM kernels for gfx950 (CDNA4), the contraction engine of the ViT-ED path.
 //
-//  gemm_nt_mfma_kernel : out = epilogue(A[M,K] . B[N,K]^T)        (Linear fwd, and dX via W^T shadow)
-//  gemm_tn_mfma_kernel : dW[N,K] = sum_m dY[m,N]^T X[m,K] (+ dbias[N] = sum_m dY[m,N]),
-//                        split over M into fp32 slabs that a small pass sums (deterministic)
+//  gemm_nt_mfma_kernel : out = epilogue(A[M,K] . B[N,K]^T)        (Linear fwd, and dX via the W^T shadow)
+//                        128 x 128 tile / 4 waves (2 x 2, each 64 x 64 = 4 x 4 v_mfma_f32_16x16x32_bf16 accumulators), or
+//                        256 x 128 / 8 waves for the plain-store K = 384, N >= 768 shapes; two LDS stages (builtin LDS-DMA,
+//                        one barrier per K-step) or a three-stage ring (inline-asm LDS-DMA, counted vmcnt, raw s_barrier)
+//  gemm_tn_mfma_kernel : dW[N,K] = sum_m dY[m,N]^T X[m,K] (+ dbias[N] = sum_m dY[m,N]) on a 128 x 128 tile, split over M
+//                        into fp32 slabs that a small pass sums (deterministic); K % 384 != 0 or M < 4,096 only
+//  gemm_tn_wide_kernel : the same product on a 128 n x 384 k tile, 8 waves (2 x 4, each 64 x 96), one workgroup per CU,
+//                        4-slot ring with three stages in flight: every dW of the embed-384 models
+//  (the row-complete N = 384 kernels with fused LayerNorm epilogues live in gemm_row.hip)
 //
-// Both: 256 threads = 4 waves (2 x 2), 128 x 128 output tile, each wave 64 x 64 = 4 x 4
-// v_mfma_f32_16x16x32_bf16 accumulators; operands staged global -> LDS with 16-byte
-// global_load_lds (LDS-DMA, no VGPR round trip), two LDS stages, one barrier per K-step, the next
-// stage's DMA in flight under the current stage's MFMAs.  LDS images are XOR-swizzled on the
-// SOURCE address (the DMA destination is lane-linear) with the matching XOR on the read, so the
+// Operands are staged global -> LDS with 16-byte global_load_lds (LDS-DMA, no VGPR round trip).  LDS images are XOR-swizzled
+// on the SOURCE address (the DMA destination is lane-linear) with the matching XOR on the read, so the
 // ds_read_b128 / ds_read_b64_tr_b16 fragment reads are bank-conflict free.
 // The NT epilogue is staged through a wave-private LDS scratch so every global access is a 16-byte,
 // row-contiguous one; its operands (residual rows, saved pre-activation, bias) are fetched after the K loop,
 // one 16-row sub-tile ahead (held across the loop they cost a workgroup per CU).
+// Timing-ablation hooks (NT_DBG_* / TN_DBG_* / TW_DBG_* / NT_TIMELINE / NT_STAGGER_US) and the VITED_NT_* / VITED_TN_*
+// environment overrides compile only into experiment builds: make VARIANT=x EXTRA="-DVITED_TUNING -D...".
 #include <stdlib.h>
+
+#include <mutex>
 
 #include "gemm_kernels.h"
 #include "gemm_nt_epilogue.h"
@@ -244,77 +251,68 @@ bool gemm_nt_mfma_supported(const void* A, int64_t lda, const void* B, int64_t l
 }
 
 template <int EPI, int BKT, int WM, int STAGES = 2>
-static void launch_nt(const bf16* a, int64_t lda, const bf16* b, int64_t ldb, int64_t M, int64_t N, int64_t K, const EpiParams& ep,
+static int launch_nt(const bf16* a, int64_t lda, const bf16* b, int64_t ldb, int64_t M, int64_t N, int64_t K, const EpiParams& ep,
                       hipStream_t s) {
     using C = NtCfg<BKT, WM>;
     const int tiles_n = (int)ceil_div64(N, BN);
     const int ntiles = (int)ceil_div64(M, C::BM) * tiles_n;
     auto kernel = gemm_nt_mfma_kernel<EPI, BKT, WM, STAGES>;
     constexpr int LDS = STAGES * C::STAGE_BYTES;
-    if (LDS > 65536) {
-        static bool done = false;
-        if (!done) {
-            (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-            done = true;
-        }
+    if (LDS > 65536) {   // dynamic LDS above 64 KB needs the opt-in: once per kernel instance, from whichever thread launches first
+        static std::once_flag once;
+        static hipError_t status = hipSuccess;
+        std::call_once(once, [&] { status = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); });
+        if (status != hipSuccess) return VITED_ERR_LAUNCH;
     }
     hipLaunchKernelGGL(kernel, dim3(ntiles), dim3(128 * WM), LDS, s, a, lda, b, ldb, M, N, K, tiles_n, ntiles, ep);
+    return VITED_OK;
 }
 
 template <int EPI>
-static void dispatch_nt(const bf16* a, int64_t lda, const bf16* b, int64_t ldb, int64_t M, int64_t N, int64_t K, const EpiParams& ep,
-                        hipStream_t s) {
-    // tuning/diagnostic overrides: VITED_NT_BK = 32 | 64, VITED_NT_WM = 2 | 4
+static int dispatch_nt(const bf16* a, int64_t lda, const bf16* b, int64_t ldb, int64_t M, int64_t N, int64_t K, const EpiParams& ep,
+                       hipStream_t s) {
+    // BK = 32 (4 workgroups / CU) pays only when the grid is large: at N = 384 (1,536 tiles) BK = 64 is 9-14 % faster
+    bool shallow = K <= 512 && N >= 768;
+    // measured (M = 65536): the 256-row tile wins 5-10 % on plain-store K = 384 GEMMs with
+    // N >= 768 (qkv, kv, fc1) and loses on the register-heavier epilogues, so it is used only there
+    bool tall = EPI == VITED_EPI_STORE && shallow && N >= 768 && M >= 8192;
+#ifdef VITED_TUNING   // experiment builds only: VITED_NT_BK = 32 | 64, VITED_NT_WM = 2 | 4, VITED_NT_STAGES = 3
     static const int force_bk = getenv("VITED_NT_BK") ? atoi(getenv("VITED_NT_BK")) : 0;
     static const int force_wm = getenv("VITED_NT_WM") ? atoi(getenv("VITED_NT_WM")) : 0;
-    static const int force_st = getenv("VITED_NT_STAGES") ? atoi(getenv("VITED_NT_STAGES")) : 0;   // 3 / 4: the asm-DMA ring
-    // BK = 32 (4 workgroups / CU) pays only when the grid is large: at N = 384 (1,536 tiles) BK = 64 is 9-14 % faster
-    const bool shallow = force_bk ? force_bk == 32 : (K <= 512 && N >= 768);
-    // measured (scratch/gemm_bench.py, M = 65536): the 256-row tile wins 5-10 % on plain-store K = 384 GEMMs with
-    // N >= 768 (qkv, kv, fc1) and loses on the register-heavier epilogues, so it is used only there
-    const bool tall = force_wm ? force_wm == 4 : (EPI == VITED_EPI_STORE && shallow && N >= 768 && M >= 8192);
+    static const int force_st = getenv("VITED_NT_STAGES") ? atoi(getenv("VITED_NT_STAGES")) : 0;
+    if (force_bk) shallow = force_bk == 32;
+    if (force_wm) tall = force_wm == 4;
     if (force_st == 3) {
-        if (shallow && tall) launch_nt<EPI, 32, 4, 3>(a, lda, b, ldb, M, N, K, ep, s);
-        else if (shallow) launch_nt<EPI, 32, 2, 3>(a, lda, b, ldb, M, N, K, ep, s);
-        else if (tall) launch_nt<EPI, 64, 4, 3>(a, lda, b, ldb, M, N, K, ep, s);
-        else launch_nt<EPI, 64, 2, 3>(a, lda, b, ldb, M, N, K, ep, s);
-        return;
+        if (shallow && tall) return launch_nt<EPI, 32, 4, 3>(a, lda, b, ldb, M, N, K, ep, s);
+        if (shallow) return launch_nt<EPI, 32, 2, 3>(a, lda, b, ldb, M, N, K, ep, s);
+        if (tall) return launch_nt<EPI, 64, 4, 3>(a, lda, b, ldb, M, N, K, ep, s);
+        return launch_nt<EPI, 64, 2, 3>(a, lda, b, ldb, M, N, K, ep, s);
     }
-    if (force_st == 5 || force_st == 6) {   // experiments: deep ring of 24 KB stages, one 8-wave workgroup per CU
-        if (force_st == 5) launch_nt<EPI, 32, 4, 5>(a, lda, b, ldb, M, N, K, ep, s);
-        else launch_nt<EPI, 32, 4, 6>(a, lda, b, ldb, M, N, K, ep, s);
-        return;
-    }
-    if (force_st == 4) {
-        if (shallow && tall) launch_nt<EPI, 32, 4, 4>(a, lda, b, ldb, M, N, K, ep, s);
-        else if (shallow) launch_nt<EPI, 32, 2, 4>(a, lda, b, ldb, M, N, K, ep, s);
-        else if (tall) launch_nt<EPI, 64, 4, 3>(a, lda, b, ldb, M, N, K, ep, s);
-        else launch_nt<EPI, 64, 2, 3>(a, lda, b, ldb, M, N, K, ep, s);
-        return;
-    }
+#endif
     // the three-stage asm-DMA ring (72 KB, 2 workgroups per CU, two stages in flight each) pays on the plain-store 256 x 128 tiles
     // only: qkv 82 -> 78 us, kv 56 -> 54; every other variant loses occupancy to it (BK = 64: 96 KB = one workgroup per CU, +50 %)
-    if (shallow && tall) launch_nt<EPI, 32, 4, 3>(a, lda, b, ldb, M, N, K, ep, s);
-    else if (shallow) launch_nt<EPI, 32, 2>(a, lda, b, ldb, M, N, K, ep, s);
-    else if (tall) launch_nt<EPI, 64, 4>(a, lda, b, ldb, M, N, K, ep, s);
-    else launch_nt<EPI, 64, 2>(a, lda, b, ldb, M, N, K, ep, s);
+    if (shallow && tall) return launch_nt<EPI, 32, 4, 3>(a, lda, b, ldb, M, N, K, ep, s);
+    if (shallow) return launch_nt<EPI, 32, 2>(a, lda, b, ldb, M, N, K, ep, s);
+    if (tall) return launch_nt<EPI, 64, 4>(a, lda, b, ldb, M, N, K, ep, s);
+    return launch_nt<EPI, 64, 2>(a, lda, b, ldb, M, N, K, ep, s);
 }
 
 int gemm_nt_mfma(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K, int epilogue,
                  const EpiParams& ep, hipStream_t s) {
     const bf16* a = (const bf16*)A;
     const bf16* b = (const bf16*)B;
+    int rc;
     switch (epilogue) {
-        case VITED_EPI_STORE: dispatch_nt<VITED_EPI_STORE>(a, lda, b, ldb, M, N, K, ep, s); break;
-        case VITED_EPI_GELU: dispatch_nt<VITED_EPI_GELU>(a, lda, b, ldb, M, N, K, ep, s); break;
-        case VITED_EPI_RESIDUAL: dispatch_nt<VITED_EPI_RESIDUAL>(a, lda, b, ldb, M, N, K, ep, s); break;
-        case VITED_EPI_MUL_GELU_GRAD: dispatch_nt<VITED_EPI_MUL_GELU_GRAD>(a, lda, b, ldb, M, N, K, ep, s); break;
-        case VITED_EPI_STORE_F32: dispatch_nt<VITED_EPI_STORE_F32>(a, lda, b, ldb, M, N, K, ep, s); break;
-        case VITED_EPI_MUL: dispatch_nt<VITED_EPI_MUL>(a, lda, b, ldb, M, N, K, ep, s); break;
-        case VITED_EPI_GELU_GRAD: dispatch_nt<VITED_EPI_GELU_GRAD>(a, lda, b, ldb, M, N, K, ep, s); break;
+        case VITED_EPI_STORE: rc = dispatch_nt<VITED_EPI_STORE>(a, lda, b, ldb, M, N, K, ep, s); break;
+        case VITED_EPI_GELU: rc = dispatch_nt<VITED_EPI_GELU>(a, lda, b, ldb, M, N, K, ep, s); break;
+        case VITED_EPI_RESIDUAL: rc = dispatch_nt<VITED_EPI_RESIDUAL>(a, lda, b, ldb, M, N, K, ep, s); break;
+        case VITED_EPI_MUL_GELU_GRAD: rc = dispatch_nt<VITED_EPI_MUL_GELU_GRAD>(a, lda, b, ldb, M, N, K, ep, s); break;
+        case VITED_EPI_STORE_F32: rc = dispatch_nt<VITED_EPI_STORE_F32>(a, lda, b, ldb, M, N, K, ep, s); break;
+        case VITED_EPI_MUL: rc = dispatch_nt<VITED_EPI_MUL>(a, lda, b, ldb, M, N, K, ep, s); break;
+        case VITED_EPI_GELU_GRAD: rc = dispatch_nt<VITED_EPI_GELU_GRAD>(a, lda, b, ldb, M, N, K, ep, s); break;
         default: return VITED_ERR_BAD_ARG;
     }
-    return vited_check_launch();
+    return rc != VITED_OK ? rc : vited_check_launch();
 }
 
 // ================================================================================================
@@ -782,8 +780,10 @@ bool gemm_tn_mfma_supported(const void* dY, int64_t lddy, const void* X, int64_t
 // Geometry per shape: the three-stage ring pays on the largest shapes only (measured, see the comment above the kernel).
 static inline bool tn_use_ring(int64_t M, int64_t N, int64_t K) {
     if (TN_FORCE_TM) return TN_FORCE_STAGES >= 3;
+#ifdef VITED_TUNING
     static const char* env = getenv("VITED_TN_RING");          // tuning override: 0 = never, 1 = always
     if (env) return atoi(env) != 0;
+#endif
     return N * K >= 1536 * 384 && M >= 16384;
 }
 
@@ -792,17 +792,23 @@ static inline bool tn_use_ring(int64_t M, int64_t N, int64_t K) {
 // The wide tile pays once a split is long enough to amortise its ring fill and its 192 KB slab (M >= 4,096 rows).
 static inline bool tn_use_wide(int64_t M, int64_t N, int64_t K) {
     if (TN_FORCE_TM) return false;
-    static const char* env = getenv("VITED_TN_WIDE");           // tuning override: 0 = never, 1 = whenever the shape allows
     if (K % 384 != 0) return false;
+#ifdef VITED_TUNING
+    static const char* env = getenv("VITED_TN_WIDE");           // tuning override: 0 = never, 1 = whenever the shape allows
     if (env) return atoi(env) != 0;
+#endif
     return M >= 4096;
 }
 
 int64_t gemm_tn_mfma_splits(int64_t M, int64_t N, int64_t K) {
     if (tn_use_wide(M, N, K)) {   // one workgroup per CU, one round
         const int64_t tiles = ceil_div64(N, 128) * (K / 384);
+        int64_t slots = 256;
+#ifdef VITED_TUNING
         static const int64_t slots_env = getenv("VITED_TN_WIDE_SLOTS") ? atoi(getenv("VITED_TN_WIDE_SLOTS")) : 0;
-        int64_t s = (slots_env ? slots_env : 256) / tiles;
+        if (slots_env) slots = slots_env;
+#endif
+        int64_t s = slots / tiles;
         const int64_t max_s = ceil_div64(M, 256);
         if (s > max_s) s = max_s;
         if (s < 1) s = 1;
@@ -812,8 +818,11 @@ int64_t gemm_tn_mfma_splits(int64_t M, int64_t N, int64_t K) {
     const bool ring = tn_use_ring(M, N, K);
     const int tm = TN_FORCE_TM ? TN_FORCE_TM : (ring ? 32 : 64);
     const int64_t tiles = ceil_div64(N, 128) * ceil_div64(K, 128);
-    static const int64_t slots_env = getenv("VITED_TN_SLOTS") ? atoi(getenv("VITED_TN_SLOTS")) : 0;   // tuning override
-    const int64_t slots = slots_env ? slots_env : (tm == 64 ? 512 : 768);
+    int64_t slots = tm == 64 ? 512 : 768;
+#ifdef VITED_TUNING
+    static const int64_t slots_env = getenv("VITED_TN_SLOTS") ? atoi(getenv("VITED_TN_SLOTS")) : 0;
+    if (slots_env) slots = slots_env;
+#endif
     int64_t s = slots / tiles;
     const int64_t max_s = ceil_div64(M, 512);
     if (s > max_s) s = max_s;
@@ -823,19 +832,21 @@ int64_t gemm_tn_mfma_splits(int64_t M, int64_t N, int64_t K) {
 }
 
 template <int TM, int STAGES>
-static void launch_tn(const void* dY, int64_t lddy, const void* X, int64_t ldx, int64_t M, int64_t N, int64_t K, int64_t splits,
+static int launch_tn(const void* dY, int64_t lddy, const void* X, int64_t ldx, int64_t M, int64_t N, int64_t K, int64_t splits,
                       float* out, float* bias_out, hipStream_t s) {
     constexpr int LDS = STAGES * 2 * TM * 128 * 2;
     const int tiles_k = (int)ceil_div64(K, 128);
     const int tiles = (int)ceil_div64(N, 128) * tiles_k;
     const int64_t rps = ceil_div64(ceil_div64(M, splits), TM) * TM;
     if (LDS > 65536) {   // dynamic LDS above 64 KB needs the opt-in (once per kernel)
-        static bool done = false;
-        if (!done) {
-            (void)hipFuncSetAttribute((const void*)gemm_tn_mfma_kernel<true, TM, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-            (void)hipFuncSetAttribute((const void*)gemm_tn_mfma_kernel<false, TM, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-            done = true;
-        }
+        static std::once_flag once;
+        static hipError_t status = hipSuccess;
+        std::call_once(once, [&] {
+            status = hipFuncSetAttribute((const void*)gemm_tn_mfma_kernel<true, TM, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+            if (status == hipSuccess)
+                status = hipFuncSetAttribute((const void*)gemm_tn_mfma_kernel<false, TM, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        });
+        if (status != hipSuccess) return VITED_ERR_LAUNCH;
     }
     if (bias_out)
         hipLaunchKernelGGL((gemm_tn_mfma_kernel<true, TM, STAGES>), dim3(tiles, (unsigned)splits), dim3(256), LDS, s,
@@ -843,39 +854,41 @@ static void launch_tn(const void* dY, int64_t lddy, const void* X, int64_t ldx, 
     else
         hipLaunchKernelGGL((gemm_tn_mfma_kernel<false, TM, STAGES>), dim3(tiles, (unsigned)splits), dim3(256), LDS, s,
                            (const bf16*)dY, lddy, (const bf16*)X, ldx, M, N, K, rps, tiles_k, out, bias_out);
+    return VITED_OK;
 }
 
-static void launch_tn_wide(const void* dY, int64_t lddy, const void* X, int64_t ldx, int64_t M, int64_t N, int64_t K, int64_t splits,
+static int launch_tn_wide(const void* dY, int64_t lddy, const void* X, int64_t ldx, int64_t M, int64_t N, int64_t K, int64_t splits,
                            float* out, float* bias_out, hipStream_t s) {
     constexpr int LDS = TW_STAGES * TW_STAGE_BYTES;
     const int tiles_k = (int)(K / 384);
     const int tiles = (int)ceil_div64(N, 128) * tiles_k;
     const int64_t rps = ceil_div64(ceil_div64(M, splits), 32) * 32;
-    static bool done = false;
-    if (!done) {
-        (void)hipFuncSetAttribute((const void*)gemm_tn_wide_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        (void)hipFuncSetAttribute((const void*)gemm_tn_wide_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        done = true;
-    }
+    static std::once_flag once;
+    static hipError_t status = hipSuccess;
+    std::call_once(once, [&] {
+        status = hipFuncSetAttribute((const void*)gemm_tn_wide_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (status == hipSuccess)
+            status = hipFuncSetAttribute((const void*)gemm_tn_wide_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    });
+    if (status != hipSuccess) return VITED_ERR_LAUNCH;
     if (bias_out)
         hipLaunchKernelGGL((gemm_tn_wide_kernel<true>), dim3(tiles, (unsigned)splits), dim3(512), LDS, s, (const bf16*)dY, lddy,
                            (const bf16*)X, ldx, M, N, K, rps, tiles_k, out, bias_out);
     else
         hipLaunchKernelGGL((gemm_tn_wide_kernel<false>), dim3(tiles, (unsigned)splits), dim3(512), LDS, s, (const bf16*)dY, lddy,
                            (const bf16*)X, ldx, M, N, K, rps, tiles_k, out, bias_out);
+    return VITED_OK;
 }
 
 int gemm_tn_mfma(const void* dY, int64_t lddy, const void* X, int64_t ldx, int64_t M, int64_t N, int64_t K, int64_t splits,
                  float* out, float* bias_out, hipStream_t s) {
-    if (tn_use_wide(M, N, K)) {
-        launch_tn_wide(dY, lddy, X, ldx, M, N, K, splits, out, bias_out, s);
-        return vited_check_launch();
-    }
+    int rc;
+    if (tn_use_wide(M, N, K)) rc = launch_tn_wide(dY, lddy, X, ldx, M, N, K, splits, out, bias_out, s);
 #if TN_FORCE_TM
-    launch_tn<TN_FORCE_TM, TN_FORCE_STAGES>(dY, lddy, X, ldx, M, N, K, splits, out, bias_out, s);
+    else rc = launch_tn<TN_FORCE_TM, TN_FORCE_STAGES>(dY, lddy, X, ldx, M, N, K, splits, out, bias_out, s);
 #else
-    if (tn_use_ring(M, N, K)) launch_tn<32, 3>(dY, lddy, X, ldx, M, N, K, splits, out, bias_out, s);
-    else launch_tn<64, 2>(dY, lddy, X, ldx, M, N, K, splits, out, bias_out, s);
+    else if (tn_use_ring(M, N, K)) rc = launch_tn<32, 3>(dY, lddy, X, ldx, M, N, K, splits, out, bias_out, s);
+    else rc = launch_tn<64, 2>(dY, lddy, X, ldx, M, N, K, splits, out, bias_out, s);
 #endif
-    return vited_check_launch();
+    return rc != VITED_OK ? rc : vited_check_launch();
 }

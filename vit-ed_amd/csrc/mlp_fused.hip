@@ -23,6 +23,8 @@
 //     inline asm so that hipcc's waitcnt bookkeeping does not drain it), two slots in flight while one is read,
 //     one raw s_barrier per slot.  Weight bytes through the CU per FLOP: 1/128 (the 128 x 128 tile GEMMs: 1/64).
 // Per 32 KB slot a wave issues 64 MFMAs (1,024 matrix cycles) against 32 KB of LDS fragment reads.
+#include <mutex>
+
 #include "common.h"
 
 #define MF_D 384
@@ -375,13 +377,13 @@ extern "C" int vited_mlp_fwd(const float* x, int64_t ldx, const float* gamma, co
     a.w1 = (const bf16*)w1; a.b1 = b1; a.w2 = (const bf16*)w2; a.b2 = b2;
     a.y = y; a.ldy = ldy; a.h = (bf16*)h; a.gd = (bf16*)gd; a.u = (bf16*)u; a.mean = mean; a.rstd = rstd;
     a.M = rows; a.eps = eps;
-    static bool attr_done = false;   // dynamic LDS above 64 KB needs the opt-in once per kernel
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)mlp_fwd_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, MF_LDS_BYTES) != hipSuccess ||
-            hipFuncSetAttribute((const void*)mlp_fwd_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, MF_LDS_BYTES) != hipSuccess)
-            return VITED_ERR_LAUNCH;
-        attr_done = true;
-    }
+    static std::once_flag once;      // dynamic LDS above 64 KB needs the opt-in once per kernel (forward thread or autograd thread)
+    static bool attr_ok = false;
+    std::call_once(once, [&] {
+        attr_ok = hipFuncSetAttribute((const void*)mlp_fwd_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, MF_LDS_BYTES) == hipSuccess &&
+                  hipFuncSetAttribute((const void*)mlp_fwd_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, MF_LDS_BYTES) == hipSuccess;
+    });
+    if (!attr_ok) return VITED_ERR_LAUNCH;
     const unsigned grid = (unsigned)ceil_div64(rows, MF_BM);
     if (save) hipLaunchKernelGGL(mlp_fwd_fused_kernel<true>, dim3(grid), dim3(256), MF_LDS_BYTES, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(mlp_fwd_fused_kernel<false>, dim3(grid), dim3(256), MF_LDS_BYTES, (hipStream_t)stream, a);

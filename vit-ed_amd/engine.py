@@ -198,7 +198,7 @@ def build_optimizer(config, model, capturable: bool = False, fused_hip: bool | N
                   weight_decay=config.TRAIN.WEIGHT_DECAY)
         if on_gpu and (fused_hip is None or fused_hip):
             from .optim import FlatAdamW
-            return FlatAdamW(groups, **kw)
+            return FlatAdamW(groups, model=model, **kw)     # the model's bf16 weight shadows are refreshed by the update kernel
         if on_gpu:
             return torch.optim.AdamW(groups, fused=True, capturable=capturable, **kw)
         return torch.optim.AdamW(groups, **kw)
@@ -279,7 +279,8 @@ class TrainStep:
       so ``lr_scheduler.step_update`` / ``set_lr`` take effect in the replayed update."""
 
     def __init__(self, model, optimizer, *, clip_grad=5.0, amp=True, criterion=None, use_graph=False,
-                 compress_bf16=False, forward_fn=None, accumulation_steps=1, lr_scheduler=None, overlap=True, group=None):
+                 compress_bf16=False, forward_fn=None, accumulation_steps=1, lr_scheduler=None, overlap=True, group=None,
+                 start_update=0):
         self.model, self.optimizer, self.clip_grad, self.amp = model, optimizer, clip_grad, amp
         self.criterion = criterion or torch.nn.BCEWithLogitsLoss()
         self.accum = max(int(accumulation_steps), 1)
@@ -300,10 +301,13 @@ class TrainStep:
                 raise ValueError('TrainStep(use_graph=True) captures optimizer.step() into a hipGraph: build the torch optimizer with '
                                  'capturable=True (engine.build_optimizer(config, model, capturable=True)) or use optim.FlatAdamW')
         self._g1 = self._g2 = self._g_opt = None
+        self._opt_signature = None
         self._static_x = self._static_y = self._static_loss = self._static_norm = None
         self._eager_steps = 0
         self._micro = 0
-        self.num_updates = 0
+        # updates done before this TrainStep existed: a resumed run passes epoch * num_steps // accumulation_steps so that the
+        # per-iteration schedule continues where it stopped (misc/engine.py:228 counts from the start of training)
+        self.num_updates = int(start_update)
         self.last_norm = None
         self._lr_tensors = None
         # a torch optimizer built with capturable=True reads its learning rate from a device scalar: keep it there in eager
@@ -382,9 +386,11 @@ class TrainStep:
                 rt.refresh_shadows(params)
 
     def _after_update(self):
-        self.num_updates += 1
+        # misc/engine.py:228: lr_scheduler.step_update((epoch * num_steps + idx) // ACCUMULATION_STEPS) runs AFTER the update of
+        # iteration idx with the count of updates done BEFORE it: 0, 1, 2, ...
         if self.lr_scheduler is not None:
             self.lr_scheduler.step_update(self.num_updates)
+        self.num_updates += 1
 
     # -- public ------------------------------------------------------------------------------
     def step(self, x, y):
@@ -413,6 +419,9 @@ class TrainStep:
                 self.flat.start_all_reduce(0, self.flat.flat.numel(), group=self.group)
             self.flat.finish_all_reduce()
             self._sync_lr()
+            if self.hip_opt and self.optimizer.shadow_signature() != self._opt_signature:
+                # a weight shadow was created (or moved) after capture: the captured descriptor table does not refresh it
+                self._capture_update()
             self._g_opt.replay()
             self.last_norm = self._static_norm
             self._after_update()
@@ -462,9 +471,23 @@ class TrainStep:
             self._g2 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._g2, pool=self._g1.pool()):
                 self._enc_bwd(self._feats, self._dfeats)
-        self._g_opt = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._g_opt, pool=self._g1.pool()):
-            self._static_norm = self._update()
+        self._capture_update()
+
+    def _capture_update(self):
+        """(Re-)capture the update graph.  Its kernels bake in the optimizer's descriptor table, i.e. the set of weight-shadow
+        buffers to refresh; ``step`` compares that set before every replay."""
+        torch.cuda.synchronize()
+        if self.hip_opt:
+            self.optimizer._descriptors()          # build the table outside the capture
+            self._opt_signature = self.optimizer.shadow_signature()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, pool=self._g1.pool()):
+            norm = self._update()
+        if self._static_norm is None:
+            self._static_norm = norm
+        elif norm.data_ptr() != self._static_norm.data_ptr():
+            self._static_norm = norm
+        self._g_opt = g
 
 
 # ---------------------------------------------------------------------------------------------
@@ -492,11 +515,17 @@ class DevicePrefetcher:
         if self.stream is None:
             return t.to(self.device)
         key = (slot, name, tuple(t.shape), t.dtype)
-        buf = self._pinned.get(key)
-        if buf is None:
-            buf = self._pinned[key] = torch.empty(t.shape, dtype=t.dtype).pin_memory()
+        ent = self._pinned.get(key)
+        if ent is None:
+            ent = self._pinned[key] = [torch.empty(t.shape, dtype=t.dtype).pin_memory(), None]
+        buf, ev = ent
+        if ev is not None:
+            ev.synchronize()               # the previous H2D copy out of this pinned slot must have executed before it is rewritten
         buf.copy_(t)
-        return buf.to(self.device, non_blocking=True)
+        out = buf.to(self.device, non_blocking=True)
+        ent[1] = torch.cuda.Event()
+        ent[1].record(self.stream)
+        return out
 
     def __iter__(self):
         import collections

@@ -92,11 +92,6 @@ class Runtime:
             self._shadow[key] = ent
         return ent[2]
 
-    def mark_shadows_current(self):
-        """The optimizer kernel rewrote parameters and shadows together (optim.FlatAdamW): nothing to recast."""
-        # entries are keyed by (id(param), tag) and validated by (version, data_ptr); a raw kernel write bumps neither
-        return None
-
     def refresh_shadows(self, params):
         """Recast every cached shadow in place with ONE multi-tensor launch (call after an optimizer step when
         replaying a graph: the captured kernels keep reading the same shadow buffers)."""

@@ -15,12 +15,16 @@ HYPER_HEADER, GROUP_WORDS, DESC_WORDS = 8, 8, 10
 
 
 class FlatAdamW(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, model=None):
+        """``model`` (the HIP ViT-ED whose parameters these are) lets the kernel refresh the model's bf16 weight shadows in the
+        same pass; without it the parameters' version counters are bumped after every update instead, so the model recasts its
+        shadows on the next forward (correct, one extra launch per weight)."""
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
         self.flat = None
-        self._model = None
+        self._model = model
+        self._loaded_step = None       # step count of a state_dict loaded before bind_flat (the reference's resume order)
         self._desc = self._desc_key = None
-        self._hyper = self._hyper_host = self._hyper_seen = None
+        self._hyper = self._hyper_seen = None
         self._norm = self._ws = None
 
     # -- wiring --------------------------------------------------------------------------------
@@ -33,27 +37,39 @@ class FlatAdamW(torch.optim.Optimizer):
         dev = flat.flat.device
         if dev.type != 'cuda':
             raise RuntimeError('FlatAdamW runs on the MI355X HIP kernel only (no CPU path); use torch.optim.AdamW for CPU parameters')
-        self.flat, self._model = flat, model
-        self.exp_avg = torch.zeros_like(flat.flat)
-        self.exp_avg_sq = torch.zeros_like(flat.flat)
+        rebind = self.flat is flat and getattr(self, 'exp_avg', None) is not None and self.exp_avg.numel() == flat.flat.numel()
+        self.flat = flat
+        if model is not None:
+            self._model = model
+        if not rebind:
+            # first binding: the moment buffers, the hyper-parameter array and the workspace are allocated ONCE - a captured
+            # update graph bakes their addresses in, so a later load_state_dict copies INTO them (below) instead of replacing them
+            self.exp_avg = torch.zeros_like(flat.flat)
+            self.exp_avg_sq = torch.zeros_like(flat.flat)
+            self._hyper = torch.zeros(HYPER_HEADER + GROUP_WORDS * len(self.param_groups), dtype=torch.float32, device=dev)
+            self._norm = torch.zeros(1, dtype=torch.float32, device=dev)
+            self._ws = torch.empty(_lib.load().vited_adamw_workspace_bytes() // 4, dtype=torch.float32, device=dev)
+            self._desc = self._desc_key = None
+        self._hyper_seen = None
         for p, off in zip(flat.params, flat.offsets):
             st = self.state[p]
             old_m, old_v = st.get('exp_avg'), st.get('exp_avg_sq')
-            st['exp_avg'] = self.exp_avg[off: off + p.numel()].view_as(p)
-            st['exp_avg_sq'] = self.exp_avg_sq[off: off + p.numel()].view_as(p)
-            if old_m is not None:
-                st['exp_avg'].copy_(old_m)
-                st['exp_avg_sq'].copy_(old_v)
-        self._hyper = torch.zeros(HYPER_HEADER + GROUP_WORDS * len(self.param_groups), dtype=torch.float32, device=dev)
-        self._hyper_host = torch.zeros_like(self._hyper, device='cpu').pin_memory()
-        self._hyper_seen = None
-        self._norm = torch.zeros(1, dtype=torch.float32, device=dev)
-        self._ws = torch.empty(_lib.load().vited_adamw_workspace_bytes() // 4, dtype=torch.float32, device=dev)
-        self._desc = self._desc_key = None
+            new_m = self.exp_avg[off: off + p.numel()].view_as(p)
+            new_v = self.exp_avg_sq[off: off + p.numel()].view_as(p)
+            if old_m is not None and old_m.data_ptr() != new_m.data_ptr():
+                new_m.copy_(old_m)
+                new_v.copy_(old_v)
+            st['exp_avg'], st['exp_avg_sq'] = new_m, new_v
+        if self._loaded_step is not None:
+            # torch.optim.AdamW keeps one step count per parameter; they advance together, so one counter serves (bias correction)
+            self._hyper[0] = float(self._loaded_step)
+            self._loaded_step = None
 
     @property
     def num_updates(self) -> int:
-        return int(self._hyper[0].item()) if self._hyper is not None else 0
+        if self._hyper is not None:
+            return int(self._hyper[0].item())
+        return int(self._loaded_step or 0)
 
     def sync_hyperparameters(self):
         """Fold ``param_groups`` (what schedulers write) into the device hyper-parameter array when they changed.  The step
@@ -62,8 +78,10 @@ class FlatAdamW(torch.optim.Optimizer):
         for g in self.param_groups:
             vals += [float(g['lr']), float(g['betas'][0]), float(g['betas'][1]), float(g['eps']), float(g['weight_decay']), 0., 0., 0.]
         if vals != self._hyper_seen:
-            self._hyper_host[HYPER_HEADER:] = torch.tensor(vals, dtype=torch.float32)
-            self._hyper[HYPER_HEADER:].copy_(self._hyper_host[HYPER_HEADER:], non_blocking=True)
+            # a fresh host tensor per change and an ordinary (host-synchronous) copy of ~16 floats: a reused pinned buffer
+            # with a non-blocking copy could be rewritten with the NEXT iteration's rate before this copy executed (the host
+            # runs ahead of the device under graph replay)
+            self._hyper[HYPER_HEADER:].copy_(torch.tensor(vals, dtype=torch.float32))
             self._hyper_seen = vals
 
     def _shadows(self):
@@ -108,10 +126,28 @@ class FlatAdamW(torch.optim.Optimizer):
                                         self._hyper.data_ptr(), float(max_norm) if max_norm else 0.0, int(zero_grad),
                                         self._norm.data_ptr(), self._ws.data_ptr(), self._ws.numel() * 4,
                                         torch.cuda.current_stream().cuda_stream), 'vited_adamw_step')
-        # the kernel rewrote the parameters and their shadows together: keep the shadow cache entries current
-        for rt in getattr(self._model, '_runtimes', {}).values():
-            rt.mark_shadows_current()
+        if not capturing:
+            self._publish_update()
         return self._norm[0]
+
+    def shadow_signature(self):
+        """What a captured update graph baked in besides this optimizer's own buffers: the set of weight-shadow buffers."""
+        return tuple(sorted((pid, tag, ent[2].data_ptr()) for rt in getattr(self._model, '_runtimes', {}).values()
+                            for (pid, tag), ent in rt._shadow.items()))
+
+    def _publish_update(self):
+        """The kernel raw-wrote the fp32 parameters (and the shadows listed in its descriptor table).  Bump every
+        parameter's version counter - anything that caches by version (a Runtime whose shadows the table did NOT cover, e.g.
+        an optimizer built without ``model``) then recasts - and mark the shadows the kernel did refresh as current."""
+        params = self.flat.params
+        torch.autograd.graph.increment_version(params)
+        refreshed = {ptr for row in (self._desc_key or ()) for ptr in row[4:6] if ptr}
+        by_id = {id(p): p for p in params}
+        for rt in getattr(self._model, '_runtimes', {}).values():
+            for (pid, tag), ent in list(rt._shadow.items()):
+                p = by_id.get(pid)
+                if p is not None and ent[2].data_ptr() in refreshed:
+                    rt._shadow[(pid, tag)] = (p._version, ent[1], ent[2])
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -143,16 +179,18 @@ class FlatAdamW(torch.optim.Optimizer):
     # -- checkpoint compatibility with torch.optim.AdamW (misc/utils.py:130-142 saves optimizer.state_dict()) ----
     def state_dict(self):
         sd = super().state_dict()
-        n = self.num_updates
+        n = self.num_updates                     # the kernel's counter once bound, else the step of a loaded checkpoint
         for st in sd['state'].values():
             st['step'] = torch.tensor(float(n))
         return sd
 
     def load_state_dict(self, state_dict):
-        flat, model = self.flat, self._model
+        """Works in either order relative to ``bind_flat`` / ``TrainStep`` (the reference resumes as: build optimizer,
+        ``load_checkpoint``, then build the loop - misc/utils.py:57-70): the loaded step count is kept until the flat buffers
+        exist.  Once bound the loaded moments are copied INTO the existing flat buffers, so a captured update graph stays valid."""
+        flat = self.flat
         super().load_state_dict(state_dict)
         steps = [float(st['step']) for st in self.state.values() if 'step' in st]
+        self._loaded_step = max(steps) if steps else None
         if flat is not None:
-            self.bind_flat(flat, model)          # re-point the moments at the flat buffers (copies the loaded values in)
-            if steps:
-                self._hyper[0] = max(steps)
+            self.bind_flat(flat)                 # copies the loaded moments into the flat buffers and applies the step count
