@@ -154,6 +154,34 @@ int vited_linear_bwd_weight(const void* dY, int64_t lddy, const void* X, int64_t
                             int64_t N, int64_t K, float* dW, float* dbias, int accumulate, float* workspace,
                             int64_t workspace_bytes, void* stream);
 
+/* ---- Linear fused with the LayerNorm on the other side of it (row-complete 384-wide tile, bf16 MFMA; gemm_row.hip) ----
+ * The reference's blocks are chains  x = x + f(norm(x))  (Block.forward vision_transformer.py:124-127, CrossBlock.forward
+ * :268-272, norm_layer :348): every residual Linear (attn.proj :38, cross_attn.proj :156, timm Mlp fc2) is followed by the next
+ * sub-block's LayerNorm, and every Linear that consumes a LayerNorm's output (qkv :34, q :151, kv :152, fc1) is followed, in
+ * backward, by that LayerNorm's backward.  These two entries do each pair in ONE kernel so the LayerNorm is not a separate
+ * pass over the fp32 residual stream.  bf16 operands, N == 384 (the embed width of every shipped pjs config), K % 32 == 0;
+ * vited_linear_layernorm_supported() tells whether a shape is covered - otherwise the caller runs vited_gemm +
+ * vited_layernorm_fwd / vited_layernorm_bwd. */
+int vited_linear_layernorm_supported(int64_t M, int64_t N, int64_t K);
+
+/* y = residual + a . w^T + bias   (fp32 [M, N], row stride ldy; residual fp32 row stride ldr, may alias y row for row)
+ * h = LayerNorm(y; gamma, beta, eps) bf16 [M, N] (row stride ldh), mean / rstd fp32 [M]   - or h == null: no LayerNorm
+ *   a bf16 [M, K] (lda), w bf16 [N, K] (ldw), bias fp32 [N] or null */
+int vited_linear_residual_layernorm_fwd(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias,
+                                        const float* residual, int64_t ldr, float* y, int64_t ldy, const float* gamma,
+                                        const float* beta, float eps, void* h, int64_t ldh, float* mean, float* rstd,
+                                        int64_t M, int64_t N, int64_t K, void* stream);
+
+/* dh = dy . wt^T  (wt = the transposed weight shadow, bf16 [N, K]: dX of y = LN(x) W^T), never written anywhere;
+ * dx_out = (dx_in ? dx_in : 0) + LN'(dh; x, mean, rstd, gamma)  fp32 (dx_out may alias dx_in), optional bf16 copy dx_lp;
+ * dgamma / dbeta: column sums of dh * xhat / dh, overwritten or (accumulate != 0) added.  workspace >= *_workspace_bytes. */
+int64_t vited_linear_layernorm_bwd_workspace_bytes(int64_t M, int64_t N);
+int vited_linear_layernorm_bwd(const void* dy, int64_t lddy, const void* wt, int64_t ldwt, const float* x, int64_t ldx,
+                               const float* gamma, const float* mean, const float* rstd, const float* dx_in,
+                               int64_t dx_in_ld, float* dx_out, int64_t dx_out_ld, void* dx_lp, int64_t dx_lp_ld,
+                               float* dgamma, float* dbeta, int accumulate, int64_t M, int64_t N, int64_t K,
+                               float* workspace, int64_t workspace_bytes, void* stream);
+
 /* ---- fused MLP branch of a block: y = x + fc2(gelu(fc1(LayerNorm(x)))) (vision_transformer.py:126,271; timm Mlp :115,:259) ---- */
 
 /* One kernel for the second half of Block.forward / CrossBlock.forward (SURVEY.md section 8(b) "optional fused mlp"): LayerNorm

@@ -19,7 +19,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import vited_oracle as vo  # noqa: E402
 
 CASES = {'T': (vo.SHAPE_T, 3), 'A_1x1': (vo.ViTEDShape(depth=1, c_depth=1), 4), 'A_2x2': (vo.ViTEDShape(depth=2, c_depth=2), 3),
-         'A_full': (vo.SHAPE_A, 2), 'rand8': (vo.SHAPE_A, 8)}
+         'A_full': (vo.SHAPE_A, 2), 'rand8': (vo.SHAPE_A, 8),
+         'H_1x1_512': (vo.ViTEDShape(img_size=512, patch_size=16, num_classes=1, num_heads=6, depth=1, c_depth=1), 2),
+         'H_4x4_512': (vo.ViTEDShape(img_size=512, patch_size=16, num_classes=1, num_heads=6, depth=4, c_depth=4), 2)}
 
 
 def oracle_taps(m, x, y, autocast):

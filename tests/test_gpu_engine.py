@@ -110,6 +110,7 @@ def test_graph_replay_equals_eager_with_lr_schedule_and_accumulation(vited, gpu,
         le, lg = [float(st.step(x, y)) for st in steps]
         assert le == lg, (it, le, lg)
     assert steps[1]._g1 is not None and steps[1]._g2 is not None and steps[0].num_updates == steps[1].num_updates == 7
+    assert steps[1].recaptures == 0          # the shadow set is stable after the eager warm-up: the update graph was captured once
     assert float(steps[0].last_norm) == float(steps[1].last_norm)
     for (n, pe), (_, pg) in zip(models[0].named_parameters(), models[1].named_parameters()):
         assert torch.equal(pe, pg), f'{n}: graph replay differs from eager launches'
@@ -414,13 +415,31 @@ def test_build_optimizer_default_under_the_reference_loop_keeps_bf16_shadows_fre
             opt.zero_grad()
             losses.append(float(loss))
         runs[kind] = (m, losses)
+    # the same loop on the CPU oracle (fp32): with stale shadows every forward after the first runs on the INITIAL weights, and the
+    # losses stay near ln 2 instead of following the (large, lr = 1e-3) first AdamW steps.  This caught torch.optim.AdamW(fused=True)
+    # too: it updates parameters without bumping their version counters (functions._install_optimizer_step_hook).
+    oracle = vo.OracleViTED(s)
+    oracle.load_state_dict({k: v.cpu() for k, v in init.items()})
+    oopt = torch.optim.AdamW(vited.engine.param_groups_no_decay_1d(oracle), lr=1e-3, betas=tuple(cfg.TRAIN.OPTIMIZER.BETAS),
+                             eps=cfg.TRAIN.OPTIMIZER.EPS, weight_decay=cfg.TRAIN.WEIGHT_DECAY)
+    g = torch.Generator().manual_seed(13)
+    want_losses = []
+    for it in range(4):
+        x = torch.randn(8, 2, 3, 64, 64, generator=g).clamp(-1, 1)
+        y = (torch.rand(8, 4, generator=g) > 0.6).float()
+        loss = bce(oracle(x), y)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(oracle.parameters(), 5.0)
+        oopt.step()
+        oopt.zero_grad()
+        want_losses.append(float(loss))
+    assert max(want_losses) > 1.0, 'the case must move the loss visibly after the first update'
     m, losses = runs['flat_hip']
-    _, want_losses = runs['torch']
-    # with stale shadows every forward after the first would run on the initial weights: same-batch-free losses would not track
-    for a, b in zip(losses, want_losses):
-        assert abs(a - b) < 2e-2 * max(1.0, abs(b)), (losses, want_losses)
-    for (n, p), (_, q) in zip(m.named_parameters(), runs['torch'][0].named_parameters()):
-        torch.testing.assert_close(p, q, rtol=2e-2, atol=2e-3, msg=lambda msg: f'{n}: {msg}')
+    for kind in ('flat_hip', 'torch'):
+        for a, b in zip(runs[kind][1], want_losses):
+            assert abs(a - b) < 3e-2 * max(1.0, abs(b)), (kind, runs[kind][1], want_losses)
+    # (parameters are not compared one by one: with lr = 1e-3 AdamW moves every element by ~1e-3 per step in the direction of
+    # the gradient's SIGN, which bf16 noise flips on near-zero gradients; the losses above are the functional check)
     x = torch.randn(4, 2, 3, 64, 64, generator=torch.Generator().manual_seed(2)).clamp(-1, 1).to(gpu)
     with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16):
         after = m.eval()(x)
@@ -465,7 +484,8 @@ def test_flat_adamw_resume_before_bind_keeps_the_step_count(vited, gpu):
         for p, g in zip(ref, grads[it]):
             p.grad = g.clone()
         topt.step()
-    ckpt = {'opt': topt.state_dict(), 'params': [p.detach().clone() for p in ref]}
+    import copy
+    ckpt = {'opt': copy.deepcopy(topt.state_dict()), 'params': [p.detach().clone() for p in ref]}    # state_dict() returns live references
     # resume: fresh parameters + FlatAdamW, load BEFORE anything binds a flat buffer
     mine = [torch.nn.Parameter(p.clone()) for p in ckpt['params']]
     opt = vited.optim.FlatAdamW(groups(mine), **kw)

@@ -538,7 +538,7 @@ def test_mlp_no_grad_fused_head_plus_unfused_tail(vited, gpu):
     vited.ops.gemm = lambda *a, **k: (calls.append(('gemm', a[0].shape[0])), real[1](*a, **k))[1]
     try:
         with torch.no_grad():
-            y, saved = F_._mlp_fwd(rt, x, gamma, beta, w1, b1, w2, b2, grad=False)
+            y, saved, _ = F_._mlp_fwd(rt, x, gamma, beta, w1, b1, w2, b2, grad=False)
     finally:
         vited.ops.mlp_fwd, vited.ops.gemm = real
     assert saved is None and ('fused', head) in calls and ('gemm', rows - head) in calls, calls

@@ -218,51 +218,95 @@ def test_gemm_bench_scale_tiles(vited, gpu, M, N, K):
     torch.testing.assert_close(acc_b.double(), dy.double().sum(0) + 2, rtol=2e-4, atol=2e-3)
 
 
-_AS_CHILD = """
-import math, sys, torch
-import torch.nn.functional as F
-sys.path.insert(0, {root!r})
-import vited_amd as vited
-ops, L = vited.ops, vited._lib
-gpu = torch.device('cuda:0')
-def _rand(shape, seed, scale=1.0, dtype=torch.float32):
-    g = torch.Generator(device='cpu').manual_seed(seed)
-    return (torch.randn(shape, generator=g) * scale).to(gpu).to(dtype)
-tol = dict(rtol=1e-2, atol=1e-2)
-for M, N in {shapes!r}:
-    K = 384
-    a = _rand((M, K), 11, dtype=torch.bfloat16)
-    w = _rand((N, K), 12, 1 / math.sqrt(K), dtype=torch.bfloat16)
-    bias = _rand((N,), 13)
-    ref = a.double() @ w.double().t() + bias.double()
-    out = ops.gemm(a, w, bias=bias)
-    assert ops.last_paths()[0] == 3, ops.last_paths()
-    torch.testing.assert_close(out.double(), ref, **tol)
-    z, u = ops.gemm(a, w, epilogue=L.EPI_GELU, bias=bias)
-    torch.testing.assert_close(z.double(), ref, **tol)
-    torch.testing.assert_close(u.double(), F.gelu(ref), **tol)
-    o32 = ops.gemm(a, w, epilogue=L.EPI_STORE_F32)
-    torch.testing.assert_close(o32.double(), ref - bias.double(), rtol=2e-4, atol=2e-4)
-    assert torch.equal(out, ops.gemm(a, w, bias=bias))
-print('AS-OK')
-"""
+# ---------------------------------------------------------------------------------------------
+# row-complete Linear + LayerNorm kernels (gemm_row.hip)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('M,K', [(64, 384), (80, 1536), (65 * 8, 384), (1000, 1152), (4096 + 33, 768), (65 * 64, 1536), (16384, 384), (13, 32)])
+def test_linear_residual_layernorm_fwd(vited, gpu, M, K):
+    """y = residual + a W^T + b and h = LayerNorm(y) in one kernel against fp64 on the same bf16-rounded operands: ragged M
+    (partial last tile, both tile heights: 64-row tiles and the 80-row tiles picked for 65-row batches), every K of the step."""
+    ops = vited.ops
+    N = 384
+    a = _rand((M, K), gpu, 1 + M, 1.0, torch.bfloat16)
+    w = _rand((N, K), gpu, 2 + K, K ** -0.5, torch.bfloat16)
+    bias, res = _rand((N,), gpu, 3, 0.5), _rand((M, N), gpu, 4, 2.0)
+    gamma, beta = 1.0 + _rand((N,), gpu, 5, 0.2), _rand((N,), gpu, 6, 0.2)
+    assert ops.linear_layernorm_supported(M, N, K, torch.bfloat16)
+    y, h, mean, rstd = ops.linear_residual_layernorm_fwd(a, w, bias, res, gamma, beta, 1e-6)
+    ref = res.double() + a.double() @ w.double().t() + bias.double()
+    torch.testing.assert_close(y.double(), ref, rtol=1e-5, atol=2e-5 * K ** 0.5)
+    mu = ref.mean(dim=1)
+    var = ref.var(dim=1, unbiased=False)
+    torch.testing.assert_close(mean.double(), mu, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(rstd.double(), (var + 1e-6).rsqrt(), rtol=1e-4, atol=1e-6)
+    href = (ref - mu[:, None]) * (var[:, None] + 1e-6).rsqrt() * gamma.double() + beta.double()
+    torch.testing.assert_close(h.double(), href, **BF16_OUT)
+    # the same numbers as the two-kernel form it replaces (same MFMA order, same LayerNorm arithmetic): bit for bit
+    if K % 64 == 0:      # (other K: the two-kernel form runs the portable fp32-FMA GEMM, another summation order)
+        y2 = ops.gemm(a, w, epilogue=vited._lib.EPI_RESIDUAL, bias=bias, residual=res)
+        h2, m2, r2 = ops.layernorm_fwd(y2, gamma, beta, 1e-6, torch.bfloat16)
+        assert torch.equal(y, y2) and torch.equal(h, h2) and torch.equal(mean, m2) and torch.equal(rstd, r2)
+    # without a LayerNorm (h == null) and in place on the residual
+    y3, h3, _, _ = ops.linear_residual_layernorm_fwd(a, w, None, res.clone(), None, None)
+    assert h3 is None
+    torch.testing.assert_close(y3.double(), ref - bias.double(), rtol=1e-5, atol=2e-5 * K ** 0.5)
+    inplace = res.clone()
+    ops.linear_residual_layernorm_fwd(a, w, bias, inplace, gamma, beta, 1e-6, out=inplace)
+    assert torch.equal(inplace, y)
 
 
-def test_gemm_persistent_activation_stationary(gpu):
-    """The opt-in persistent kernel for K = 384 Linears (gemm_nt_as.hip, VITED_NT=as): unit ranges that
-    start mid m-tile, span m-tile changes (A reload) and wrap the weight ring many times must all give
-    the right answer - every output element against fp64 on the same bf16-rounded operands.  The
-    kernel family is latched from the environment at the first GEMM of a process, so the checks run in
-    ONE child interpreter with VITED_NT=as (one extra GPU process, within the box's limit)."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    shapes = [(256, 64), (768, 1536), (25600, 1152), (66560, 384), (16640, 768)]
-    code = _AS_CHILD.format(root=root, shapes=shapes)
-    r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, VITED_NT='as'), capture_output=True, text=True,
-                       timeout=600)
-    assert r.returncode == 0 and 'AS-OK' in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+@pytest.mark.parametrize('M,K', [(64, 384), (80, 1536), (65 * 8, 1152), (1000, 768), (4096 + 33, 1536), (65 * 64, 384), (16384, 1152)])
+def test_linear_layernorm_bwd(vited, gpu, M, K):
+    """dx = dx_in + LN'(dy Wt^T) with the column sums, one kernel, against fp64 autograd through LayerNorm on the same
+    bf16-rounded operands.  d(LayerNorm output) stays fp32 inside the kernel, so it is MORE accurate than the two-kernel form
+    (which rounds it to bf16): both are checked against fp64, the fused one at the tighter tolerance."""
+    ops = vited.ops
+    N = 384
+    dy = _rand((M, K), gpu, 11 + M, 1.0, torch.bfloat16)
+    wt = _rand((N, K), gpu, 12 + K, K ** -0.5, torch.bfloat16)
+    x = _rand((M, N), gpu, 13, 1.5) + 0.3
+    gamma = 1.0 + _rand((N,), gpu, 14, 0.2)
+    dx_in = _rand((M, N), gpu, 15, 1.0)
+    xd = x.double().requires_grad_(True)
+    gd = gamma.double().requires_grad_(True)
+    bd = torch.zeros(N, dtype=torch.float64, device=gpu, requires_grad=True)
+    yd = F.layer_norm(xd, (N,), gd, bd, 1e-6)
+    dh = dy.double() @ wt.double().t()
+    yd.backward(dh)
+    mu = x.double().mean(dim=1)
+    rs = (x.double().var(dim=1, unbiased=False) + 1e-6).rsqrt()
+    mean, rstd = mu.float(), rs.float()
+    dx, dx_lp, dg, db = ops.linear_layernorm_bwd(dy, wt, x, gamma, mean, rstd, dx_in=dx_in, want_lp=True)
+    want = xd.grad + dx_in.double()
+    scale = float(want.abs().max())
+    torch.testing.assert_close(dx.double(), want, rtol=1e-4, atol=1e-5 * scale)
+    assert torch.equal(dx_lp, dx.to(torch.bfloat16))
+    torch.testing.assert_close(dg.double(), gd.grad, rtol=1e-4, atol=1e-5 * float(gd.grad.abs().max()) * M ** 0.5)
+    torch.testing.assert_close(db.double(), bd.grad, rtol=1e-4, atol=1e-5 * float(bd.grad.abs().max()) * M ** 0.5)
+    # no incoming residual gradient, no bf16 copy, accumulate onto existing column sums, dx written in place of dx_in
+    acc_g, acc_b = torch.full((N,), 2.0, device=gpu), torch.full((N,), -1.0, device=gpu)
+    dx2, lp2, _, _ = ops.linear_layernorm_bwd(dy, wt, x, gamma, mean, rstd, dgamma=acc_g, dbeta=acc_b)
+    assert lp2 is None
+    torch.testing.assert_close(dx2.double(), xd.grad, rtol=1e-4, atol=1e-5 * scale)
+    torch.testing.assert_close(acc_g - 2.0, dg, rtol=1e-4, atol=1e-4 * float(dg.abs().max()))
+    torch.testing.assert_close(acc_b + 1.0, db, rtol=1e-4, atol=1e-4 * float(db.abs().max()))
+    buf = dx_in.clone()
+    ops.linear_layernorm_bwd(dy, wt, x, gamma, mean, rstd, dx_in=buf, dx_out=buf)
+    assert torch.equal(buf, dx)
+    # the two-kernel form, for scale: same result within the bf16 rounding of dh it adds
+    dh_lp = ops.gemm(dy, wt)
+    dx_u, _, dg_u, _ = ops.layernorm_bwd(dh_lp, x, gamma, mean, rstd, dx_in=dx_in)
+    torch.testing.assert_close(dx_u, dx, rtol=2e-2, atol=2e-2 * scale)
+
+
+def test_linear_layernorm_rejects_other_shapes(vited, gpu):
+    ops = vited.ops
+    assert not ops.linear_layernorm_supported(128, 768, 384, torch.bfloat16)      # N != 384
+    assert not ops.linear_layernorm_supported(128, 384, 48, torch.bfloat16)       # K % 32
+    assert not ops.linear_layernorm_supported(128, 384, 384, torch.float32)       # fp32 exact path keeps the separate kernels
+    a, w = _rand((64, 384), gpu, 1, 1.0, torch.bfloat16), _rand((768, 384), gpu, 2, 0.05, torch.bfloat16)
+    with pytest.raises(RuntimeError, match='unsupported'):
+        ops.linear_residual_layernorm_fwd(a, w, None, torch.zeros(64, 768, device=gpu))
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])

@@ -1,0 +1,361 @@
+// Row-complete bf16 MFMA GEMM for the 384-wide residual stream, with LayerNorm fused into the epilogue.
+//
+//   MODE_FWD  y = residual + A[M,K] . W[384,K]^T + bias   (fp32)        - proj / cross-proj / fc2 + residual
+//             h = LayerNorm(y; gamma, beta, eps) (bf16), mean, rstd       - the NEXT sub-block's norm (models/vision_transformer.py:
+//                                                                           124-127, 268-272: x = x + f(norm(x)) chains)
+//   MODE_BWD  dh = dY[M,K] . Wt[384,K]^T                                  - dX of a Linear that consumed a LayerNorm's output
+//             dx = dx_in + LN'(dh; x, mean, rstd, gamma) (fp32, + bf16 copy), dgamma / dbeta partial column sums
+//
+// Why: LayerNorm needs whole rows, and the 128 x 128 tile kernels (gemm_mfma.hip) split the 384 columns over three workgroups,
+// so every LayerNorm was its own streaming pass over the fp32 residual stream (196 launches, 4.9 ms of a 30 ms step, round 2).
+// Here one workgroup owns BM complete rows: 4 waves side by side, each BM rows x 96 columns (MT x 6 accumulators of
+// v_mfma_f32_16x16x32_bf16), K-steps of 32 staged by LDS-DMA into the swizzled two-stage image of the other NT kernels
+// (A panel BM x 64 B + the whole W panel 384 x 64 B = 24 KB per step).  Two workgroups per CU (57-59 KB of LDS, <= 256 VGPRs),
+// so one workgroup's HBM-bound epilogue runs under the other's staging-bound main loop.
+//
+// The product is issued transposed (W fragment as the A operand): a lane then holds 4 CONSECUTIVE columns of one row and the
+// tile goes to an fp32 LDS scratch (32 rows x 388 floats, reusing the stage buffers) as 16-byte stores; from there the
+// epilogue is the LayerNorm kernels' own row loop (layernorm.hip): a 32-lane half-wave owns a row, 3 float4 per lane, all global
+// traffic in full lines, row statistics by 5-step butterflies.  dh never reaches HBM and is never rounded to bf16.
+//
+// BM = 64 (MT = 4) or 80 (MT = 5), chosen per M so that the tiles fill the chip's 512 resident slots in the fewest rounds
+// (65,536 rows = 1024 x 64: two full rounds; 66,560 rows = 832 x 80: two rounds, where 1040 x 64 would need three).
+#include "gemm_kernels.h"
+#include "gemm_lds.h"
+
+#define ROW_N 384
+#define ROW_LD 388      // floats per scratch row: 16-byte aligned rows; 388 mod 32 = 4 spreads the 8-lane groups of ds_write_b128 over the banks
+#define ROW_PASS 32     // rows per epilogue pass (scratch = 32 x 388 x 4 = 49,664 B <= the two stages)
+
+enum { ROW_MODE_FWD = 0, ROW_MODE_BWD = 1 };
+
+struct RowArgs {
+    const bf16* A; int64_t lda;
+    const bf16* W; int64_t ldw;
+    int64_t M; int K;
+    // forward
+    const float* bias; const float* residual; int64_t ldr;
+    float* y; int64_t ldy;
+    const float* gamma; const float* beta; float eps;
+    bf16* h; int64_t ldh; float* mean; float* rstd;
+    // backward
+    const float* x; int64_t ldx; const float* mean_in; const float* rstd_in;
+    const float* dx_in; int64_t ldxi; float* dx; int64_t lddx; bf16* dx_lp; int64_t ldlp;
+    float* partial;     // [tiles][2][384]
+};
+
+template <int MT> struct RowCfg {
+    static constexpr int BM = 16 * MT;
+    static constexpr int A_BYTES = BM * 64;
+    static constexpr int STAGE_BYTES = A_BYTES + ROW_N * 64;
+    static constexpr int LDS_BYTES = 2 * STAGE_BYTES;
+    static constexpr int NPASS = (BM + ROW_PASS - 1) / ROW_PASS;
+    static_assert(LDS_BYTES >= ROW_PASS * ROW_LD * 4, "epilogue scratch must fit the stage buffers");
+    static_assert(LDS_BYTES >= 8 * 2 * ROW_N * 4, "column-partial combine must fit the stage buffers");
+};
+
+__device__ __forceinline__ float row_half_sum(float v) {   // over the 32 lanes of a half-wave
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+struct RowFwdIn { f32x4 res[3]; };
+struct RowBwdIn { f32x4 x[3], din[3]; float mu, rs; };
+
+template <int MODE, int MT>
+__global__ void __launch_bounds__(256, 2)
+gemm_row_kernel(const RowArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using C = NtCfg<32>;
+    using R = RowCfg<MT>;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t m0 = (int64_t)blockIdx.x * R::BM;
+
+    f32x4 acc[MT][6];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- LDS-DMA roles: a piece = 16 rows x 64 B = one wave-instruction.  Wave w stages A piece w (wave 0 also piece 4 when
+    // MT = 5) and W pieces 6 w .. 6 w + 5.  Lane (rsub, cp) lands at row rsub, 16-byte slot cp, and fetches source chunk
+    // cp ^ swz(row): the swizzle only depends on (row >> 2) & 3 = (rsub >> 2) & 3 for every piece.
+    const int rsub = lane >> 2, cp = lane & 3;
+    const int csrc = (cp ^ C::swz(rsub)) * 8;
+    int64_t ar = m0 + wave * 16 + rsub;
+    ar = ar < a.M ? ar : a.M - 1;
+    const bf16* pa = a.A + ar * a.lda + csrc;
+    const bf16* pa4 = pa;
+    if (MT == 5) {
+        int64_t ar4 = m0 + 64 + rsub;
+        ar4 = ar4 < a.M ? ar4 : a.M - 1;
+        pa4 = a.A + ar4 * a.lda + csrc;
+    }
+    const bf16* pb = a.W + (int64_t)(wave * 96 + rsub) * a.ldw + csrc;
+    const int64_t pstep = 16 * a.ldw;
+    auto stage_load = [&](int t, char* stage) {
+        const int k0 = t * 32;
+        glds16(pa + k0, stage + wave * 1024);
+        if (MT == 5 && wave == 0) glds16(pa4 + k0, stage + 4 * 1024);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) glds16(pb + i * pstep + k0, stage + R::A_BYTES + (wave * 6 + i) * 1024);
+    };
+
+    // ---- fragment offsets: row (16 i + fr) / (96 wave + 16 j + fr), k-chunk fq; the swizzle again depends on fr only
+    const int fr = lane & 15, fq = lane >> 4;
+    const int aoff = C::off(fr, fq);
+    const int boff = R::A_BYTES + wave * 96 * 64 + C::off(fr, fq);
+
+    const int nk = a.K / 32;
+    stage_load(0, smem);
+    for (int t = 0; t < nk; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();   // stage t landed for every wave; everyone is done reading stage t - 1
+        if (t + 1 < nk) stage_load(t + 1, smem + ((t + 1) & 1) * R::STAGE_BYTES);
+        const char* st = smem + (t & 1) * R::STAGE_BYTES;
+        bf16x8 af[MT], bf_[6];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) af[i] = *(const bf16x8*)(st + aoff + i * 1024);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) bf_[j] = *(const bf16x8*)(st + boff + j * 1024);
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)   // transposed product: lane holds row (16 i + fr), columns 96 wave + 16 j + 4 fq + (0..3)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf_[j], af[i], acc[i][j], 0, 0, 0);
+    }
+
+    // ---- epilogue: 32 rows per pass through the fp32 scratch, then the LayerNorm row loop (half-wave per row)
+    float* sc = (float*)smem;
+    const int hl = lane & 31;
+    const int hw = wave * 2 + (lane >> 5);          // half-wave 0..7: rows hw, hw + 8, hw + 16, hw + 24 of a pass
+    const float inv_d = 1.0f / ROW_N;
+    f32x4 gm[3], bt[3], bs[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int c = (j * 32 + hl) * 4;
+        gm[j] = a.gamma ? *(const f32x4*)(a.gamma + c) : f32x4{1.f, 1.f, 1.f, 1.f};
+        bt[j] = (MODE == ROW_MODE_FWD && a.beta) ? *(const f32x4*)(a.beta + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        bs[j] = (MODE == ROW_MODE_FWD && a.bias) ? *(const f32x4*)(a.bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    f32x4 dg[3], db[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        dg[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        db[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    auto load_fwd = [&](RowFwdIn& in, int64_t m) {
+        const bool ok = m < a.M;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            in.res[j] = ok ? *(const f32x4*)(a.residual + m * a.ldr + (j * 32 + hl) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    auto load_bwd = [&](RowBwdIn& in, int64_t m) {
+        const bool ok = m < a.M;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int c = (j * 32 + hl) * 4;
+            in.x[j] = ok ? *(const f32x4*)(a.x + m * a.ldx + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+            in.din[j] = (ok && a.dx_in) ? *(const f32x4*)(a.dx_in + m * a.ldxi + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        in.mu = ok ? a.mean_in[m] : 0.f;
+        in.rs = ok ? a.rstd_in[m] : 0.f;
+    };
+    auto row_fwd = [&](const RowFwdIn& in, int r, int64_t m) {
+        if (m >= a.M) return;
+        f32x4 v[3];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int c = (j * 32 + hl) * 4;
+            v[j] = *(const f32x4*)(sc + r * ROW_LD + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[j][e] += bs[j][e];
+                v[j][e] += in.res[j][e];
+            }
+            *(f32x4*)(a.y + m * a.ldy + c) = v[j];
+            s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+        }
+        if (!a.h) return;
+        const float mu = row_half_sum(s) * inv_d;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = v[j][e] - mu;
+                q = fmaf(d, d, q);
+            }
+        const float rs = rsqrtf(row_half_sum(q) * inv_d + a.eps);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int c = (j * 32 + hl) * 4;
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (bf16)((v[j][e] - mu) * rs * gm[j][e] + bt[j][e]);
+            *(bf16x4*)(a.h + m * a.ldh + c) = o;
+        }
+        if (hl == 0) {
+            a.mean[m] = mu;
+            a.rstd[m] = rs;
+        }
+    };
+    auto row_bwd = [&](const RowBwdIn& in, int r, int64_t m) {
+        if (m >= a.M) return;
+        f32x4 xh[3], gg[3];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int c = (j * 32 + hl) * 4;
+            const f32x4 d = *(const f32x4*)(sc + r * ROW_LD + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                xh[j][e] = (in.x[j][e] - in.mu) * in.rs;
+                gg[j][e] = d[e] * gm[j][e];
+                s1 += gg[j][e];
+                s2 = fmaf(gg[j][e], xh[j][e], s2);
+                dg[j][e] = fmaf(d[e], xh[j][e], dg[j][e]);
+                db[j][e] += d[e];
+            }
+        }
+        const float c1 = row_half_sum(s1) * inv_d, c2 = row_half_sum(s2) * inv_d;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int c = (j * 32 + hl) * 4;
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = in.rs * (gg[j][e] - c1 - xh[j][e] * c2) + in.din[j][e];
+            *(f32x4*)(a.dx + m * a.lddx + c) = v;
+            if (a.dx_lp) *(bf16x4*)(a.dx_lp + m * a.ldlp + c) = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+        }
+    };
+
+#pragma unroll
+    for (int p = 0; p < R::NPASS; ++p) {
+        const int rows_here = (R::BM - p * ROW_PASS) < ROW_PASS ? (R::BM - p * ROW_PASS) : ROW_PASS;   // 32 or 16: compile-time after unrolling
+        const int64_t mp = m0 + p * ROW_PASS;
+        RowFwdIn fcur, fnxt;
+        RowBwdIn bcur, bnxt;
+        // the first row's operands travel under the dump and its two barriers
+        if (MODE == ROW_MODE_FWD) load_fwd(fcur, mp + hw);
+        else load_bwd(bcur, mp + hw);
+        __syncthreads();       // every wave is done with the LDS (main loop's last stage / the previous pass's rows)
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+            const int i = 2 * p + ii;
+            if (i < MT) {
+#pragma unroll
+                for (int j = 0; j < 6; ++j) *(f32x4*)(sc + (ii * 16 + fr) * ROW_LD + wave * 96 + j * 16 + fq * 4) = acc[i][j];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = hw + 8 * k;
+            if (8 * k >= rows_here) break;
+            const bool more = 8 * (k + 1) < rows_here;
+            if (MODE == ROW_MODE_FWD) {
+                if (more) load_fwd(fnxt, mp + r + 8);
+                row_fwd(fcur, r, mp + r);
+                if (more) fcur = fnxt;
+            } else {
+                if (more) load_bwd(bnxt, mp + r + 8);
+                row_bwd(bcur, r, mp + r);
+                if (more) bcur = bnxt;
+            }
+        }
+    }
+
+    if (MODE == ROW_MODE_BWD) {
+        // the 8 half-waves' column partials -> one [2][384] row per workgroup (summed over workgroups by ln_bwd_finish)
+        __syncthreads();
+        float* my = sc + hw * 2 * ROW_N;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int c = (j * 32 + hl) * 4;
+            *(f32x4*)(my + c) = dg[j];
+            *(f32x4*)(my + ROW_N + c) = db[j];
+        }
+        __syncthreads();
+        float* out = a.partial + (int64_t)blockIdx.x * 2 * ROW_N;
+        for (int c = threadIdx.x; c < 2 * ROW_N; c += 256) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) s += sc[w * 2 * ROW_N + c];
+            out[c] = s;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+static inline int row_mt(int64_t M) {
+    // rounds of 512 resident workgroups (2 per CU) x rows per tile: the smaller makespan wins
+    const int64_t c4 = ceil_div64(ceil_div64(M, 64), 512) * 64, c5 = ceil_div64(ceil_div64(M, 80), 512) * 80;
+    return c5 < c4 ? 5 : 4;
+}
+
+static inline int64_t row_tiles(int64_t M) { return ceil_div64(M, 16 * row_mt(M)); }
+
+static bool row_shape_ok(int64_t M, int64_t N, int64_t K) { return N == ROW_N && K >= 32 && K % 32 == 0 && K <= (1 << 20) && M >= 1 && M < ((int64_t)1 << 31); }
+
+extern "C" int vited_linear_layernorm_supported(int64_t M, int64_t N, int64_t K) { return row_shape_ok(M, N, K) ? 1 : 0; }
+
+template <int MODE>
+static int row_launch(const RowArgs& a, hipStream_t s) {
+    const int mt = row_mt(a.M);
+    const unsigned tiles = (unsigned)row_tiles(a.M);
+    if (mt == 5) hipLaunchKernelGGL((gemm_row_kernel<MODE, 5>), dim3(tiles), dim3(256), RowCfg<5>::LDS_BYTES, s, a);
+    else hipLaunchKernelGGL((gemm_row_kernel<MODE, 4>), dim3(tiles), dim3(256), RowCfg<4>::LDS_BYTES, s, a);
+    return vited_check_launch();
+}
+
+static inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+extern "C" int vited_linear_residual_layernorm_fwd(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias,
+                                                   const float* residual, int64_t ldr, float* y, int64_t ldy, const float* gamma,
+                                                   const float* beta, float eps, void* h, int64_t ldh, float* mean, float* rstd,
+                                                   int64_t M, int64_t N, int64_t K, void* stream) {
+    if (!a || !w || !residual || !y || M <= 0 || N <= 0 || K <= 0 || lda < K || ldw < K || ldr < N || ldy < N) return VITED_ERR_BAD_ARG;
+    if (h && (!gamma || !beta || !mean || !rstd || ldh < N)) return VITED_ERR_BAD_ARG;
+    if (!row_shape_ok(M, N, K)) return VITED_ERR_UNSUPPORTED;
+    if ((lda & 7) || (ldw & 7) || (ldr & 3) || (ldy & 3) || (h && (ldh & 3))) return VITED_ERR_UNSUPPORTED;
+    if (!al16(a) || !al16(w) || !al16(residual) || !al16(y) || !al16(bias) || !al16(gamma) || !al16(beta) || ((uintptr_t)h & 7))
+        return VITED_ERR_BAD_ARG;
+    RowArgs r = {};
+    r.A = (const bf16*)a; r.lda = lda; r.W = (const bf16*)w; r.ldw = ldw; r.M = M; r.K = (int)K;
+    r.bias = bias; r.residual = residual; r.ldr = ldr; r.y = y; r.ldy = ldy;
+    r.gamma = gamma; r.beta = beta; r.eps = eps; r.h = (bf16*)h; r.ldh = ldh; r.mean = mean; r.rstd = rstd;
+    return row_launch<ROW_MODE_FWD>(r, (hipStream_t)stream);
+}
+
+// layernorm.hip
+int ln_bwd_finish(const float* partial, int nparts, int dim, float* dgamma, float* dbeta, int accumulate, hipStream_t s);
+
+extern "C" int64_t vited_linear_layernorm_bwd_workspace_bytes(int64_t M, int64_t N) {
+    return N == ROW_N && M >= 1 ? row_tiles(M) * 2 * ROW_N * (int64_t)sizeof(float) : 0;
+}
+
+extern "C" int vited_linear_layernorm_bwd(const void* dy, int64_t lddy, const void* wt, int64_t ldwt, const float* x, int64_t ldx,
+                                          const float* gamma, const float* mean, const float* rstd, const float* dx_in,
+                                          int64_t dx_in_ld, float* dx_out, int64_t dx_out_ld, void* dx_lp, int64_t dx_lp_ld,
+                                          float* dgamma, float* dbeta, int accumulate, int64_t M, int64_t N, int64_t K,
+                                          float* workspace, int64_t workspace_bytes, void* stream) {
+    if (!dy || !wt || !x || !gamma || !mean || !rstd || !dx_out || !dgamma || !dbeta || M <= 0 || N <= 0 || K <= 0) return VITED_ERR_BAD_ARG;
+    if (lddy < K || ldwt < K || ldx < N || dx_out_ld < N || (dx_in && dx_in_ld < N) || (dx_lp && dx_lp_ld < N)) return VITED_ERR_BAD_ARG;
+    if (!row_shape_ok(M, N, K)) return VITED_ERR_UNSUPPORTED;
+    if ((lddy & 7) || (ldwt & 7) || (ldx & 3) || (dx_out_ld & 3) || (dx_in && (dx_in_ld & 3)) || (dx_lp && (dx_lp_ld & 3))) return VITED_ERR_UNSUPPORTED;
+    if (!al16(dy) || !al16(wt) || !al16(x) || !al16(gamma) || !al16(dx_in) || !al16(dx_out) || ((uintptr_t)dx_lp & 7)) return VITED_ERR_BAD_ARG;
+    if (!workspace || workspace_bytes < vited_linear_layernorm_bwd_workspace_bytes(M, N)) return VITED_ERR_WORKSPACE;
+    RowArgs r = {};
+    r.A = (const bf16*)dy; r.lda = lddy; r.W = (const bf16*)wt; r.ldw = ldwt; r.M = M; r.K = (int)K;
+    r.gamma = gamma; r.x = x; r.ldx = ldx; r.mean_in = mean; r.rstd_in = rstd;
+    r.dx_in = dx_in; r.ldxi = dx_in_ld; r.dx = dx_out; r.lddx = dx_out_ld; r.dx_lp = (bf16*)dx_lp; r.ldlp = dx_lp_ld;
+    r.partial = workspace;
+    const int rc = row_launch<ROW_MODE_BWD>(r, (hipStream_t)stream);
+    if (rc != VITED_OK) return rc;
+    return ln_bwd_finish(workspace, (int)row_tiles(M), ROW_N, dgamma, dbeta, accumulate, (hipStream_t)stream);
+}

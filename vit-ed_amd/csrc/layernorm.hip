@@ -246,6 +246,13 @@ ln_bwd_finish_kernel(const float* __restrict__ partial, int nparts, int width, f
     }
 }
 
+// shared with the fused Linear + LayerNorm backward (gemm_row.hip): sum [nparts][2][dim] partial rows onto dgamma / dbeta
+int ln_bwd_finish(const float* partial, int nparts, int dim, float* dgamma, float* dbeta, int accumulate, hipStream_t s) {
+    hipLaunchKernelGGL(ln_bwd_finish_kernel, dim3((2 * dim + 15) / 16), dim3(16 * LNF_GROUPS), 0, s, partial, nparts, 2 * dim, dgamma, dbeta, dim,
+                       accumulate);
+    return vited_check_launch();
+}
+
 static inline int64_t ln_bwd_blocks(int64_t rows) {
     int64_t b = ceil_div64(rows, 8 * 4);  // >= 4 rows per half-wave
     if (b > 768) b = 768;                 // 3 workgroups per CU: measured best of 512 / 768 / 1024 / 1536 / 2048 at 66,560 rows

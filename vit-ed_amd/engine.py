@@ -262,6 +262,12 @@ def _decoder_only_parameters(model):
     return out
 
 
+# Graph capture must not make OTHER threads' HIP calls illegal: RCCL's watchdog thread polls the events of finished collectives
+# (hipEventQuery) whenever it likes, and under the default "global" capture mode such a query during a capture kills the process
+# group ("operation not permitted when stream is capturing").  Only this thread's own calls are restricted.
+_CAPTURE_MODE = 'thread_local'
+
+
 class TrainStep:
     """forward (autocast) -> BCE-with-logits / accumulation_steps -> backward -> flat all-reduce -> clip 5.0 ->
     optimizer step -> lr_scheduler.step_update -> zero   (misc/engine.py:202-231).
@@ -302,6 +308,7 @@ class TrainStep:
                                  'capturable=True (engine.build_optimizer(config, model, capturable=True)) or use optim.FlatAdamW')
         self._g1 = self._g2 = self._g_opt = None
         self._opt_signature = None
+        self.recaptures = 0
         self._static_x = self._static_y = self._static_loss = self._static_norm = None
         self._eager_steps = 0
         self._micro = 0
@@ -422,6 +429,7 @@ class TrainStep:
             if self.hip_opt and self.optimizer.shadow_signature() != self._opt_signature:
                 # a weight shadow was created (or moved) after capture: the captured descriptor table does not refresh it
                 self._capture_update()
+                self.recaptures += 1
             self._g_opt.replay()
             self.last_norm = self._static_norm
             self._after_update()
@@ -462,14 +470,14 @@ class TrainStep:
             rt.pinned = True
         split = self.split and torch.is_tensor(x) and x.dim() == 5
         self._g1 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._g1):
+        with torch.cuda.graph(self._g1, capture_error_mode=_CAPTURE_MODE):
             if split:
                 self._static_loss, self._feats, self._dfeats = self._fwd_dec_bwd(self._static_x, self._static_y)
             else:
                 self._static_loss = self._fwd_bwd(self._static_x, self._static_y)
         if split:
             self._g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._g2, pool=self._g1.pool()):
+            with torch.cuda.graph(self._g2, pool=self._g1.pool(), capture_error_mode=_CAPTURE_MODE):
                 self._enc_bwd(self._feats, self._dfeats)
         self._capture_update()
 
@@ -481,7 +489,7 @@ class TrainStep:
             self.optimizer._descriptors()          # build the table outside the capture
             self._opt_signature = self.optimizer.shadow_signature()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, pool=self._g1.pool()):
+        with torch.cuda.graph(g, pool=self._g1.pool(), capture_error_mode=_CAPTURE_MODE):
             norm = self._update()
         if self._static_norm is None:
             self._static_norm = norm

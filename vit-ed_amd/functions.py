@@ -36,6 +36,31 @@ DEC_SHARED_KEYS = ('patch_embed.proj.weight', 'patch_embed.proj.bias', 'pos_embe
                    'norm.bias', 'head.weight', 'head.bias')
 
 
+_step_hook_installed = False
+
+
+def _install_optimizer_step_hook():
+    """The bf16 weight shadows are validated by the parameters' version counters.  ``torch.optim.*(fused=True)`` updates the
+    parameters WITHOUT bumping them (measured: ``p._version`` is unchanged by a fused AdamW step, while the default / foreach
+    implementations bump it), so a model trained by such an optimizer in the reference's own loop would keep running on its
+    initial weights.  A global optimizer post-step hook bumps the versions of whatever any optimizer just stepped; optimizers
+    that refresh the shadows themselves (optim.FlatAdamW) opt out with ``manages_weight_shadows``."""
+    global _step_hook_installed
+    if _step_hook_installed:
+        return
+    from torch.optim.optimizer import register_optimizer_step_post_hook
+
+    def bump(optimizer, args, kwargs):
+        if getattr(optimizer, 'manages_weight_shadows', False):
+            return
+        params = [p for g in optimizer.param_groups for p in g['params'] if torch.is_tensor(p)]
+        if params:
+            torch.autograd.graph.increment_version(params)
+
+    register_optimizer_step_post_hook(bump)
+    _step_hook_installed = True
+
+
 class Runtime:
     """Per-model launch context: static shape, activation dtype and the low-precision weight shadows."""
 
@@ -54,10 +79,13 @@ class Runtime:
         self.attn_store = {}        # (kind, block index, 'attn' | 'cross_attn') -> {'attn': ..., 'grad': ...}
         self.cls_tail = os.environ.get('VITED_CLS_TAIL', '1') != '0'   # last decoder block on the cls rows only (exact; see _dec_block_fwd)
         self.fused_mlp = os.environ.get('VITED_FUSED_MLP', '1') != '0'   # vited_mlp_fwd on the no-grad paths
+        self.fused_ln = os.environ.get('VITED_FUSED_LN', '1') != '0'     # LayerNorm inside the neighbouring Linear's kernel (gemm_row.hip)
         self.tap = None             # test/diagnostic: a dict that receives clones of per-block activations and gradients
         self.pinned = False         # a captured hipGraph reads the shadow buffers: never free one, only refresh in place
         self._retired = []
         self._shadow = {}
+        if not self.exact:
+            _install_optimizer_step_hook()
 
     @property
     def exact(self):
@@ -168,6 +196,45 @@ def _linear_bwd(rt, dy, x_saved, w, b=None, want_dx=True, aux=None):
     return dx, dw, db
 
 
+def _row_kernel_ok(rt, m, n, k, dtype, *rowwise):
+    """The row-complete Linear + LayerNorm kernels (gemm_row.hip) take this product: bf16, 384 output columns, dense rows."""
+    return (rt.fused_ln and not rt.exact and ops.linear_layernorm_supported(m, n, k, dtype)
+            and all(t is None or (t.dim() == 2 and t.stride(1) == 1 and t.stride(0) % 4 == 0) for t in rowwise))
+
+
+def _res_linear(rt, a, w, bias, residual, ln=None):
+    """y = residual + a W^T + bias (fp32) and, with ``ln`` = (gamma, beta) of the LayerNorm that FOLLOWS on the residual stream
+    (the next sub-block's norm: vision_transformer.py:124-127, 268-272), also (h, mean, rstd) = LayerNorm(y) - in ONE kernel when
+    the row-complete kernel covers the shape, otherwise as vited_gemm(RESIDUAL) + vited_layernorm_fwd.
+    Returns (y, (h, mean, rstd) | None)."""
+    wsh = rt.weight(w)
+    if ln is not None and _row_kernel_ok(rt, a.shape[0], wsh.shape[0], a.shape[1], a.dtype, a, residual):
+        y, h, mean, rstd = ops.linear_residual_layernorm_fwd(a, wsh, bias, residual, ln[0], ln[1], LN_EPS)
+        return y, (h, mean, rstd)
+    y = ops.gemm(a, wsh, epilogue=EPI_RESIDUAL, bias=bias, residual=residual)
+    return y, (ops.layernorm_fwd(y, ln[0], ln[1], LN_EPS, rt.act_dtype) if ln is not None else None)
+
+
+def _linear_ln_bwd(rt, dy, h_saved, w, bias, x, gamma, beta, mean, rstd, dx_in=None, dx_out=None, want_lp=True):
+    """Backward of  y = LayerNorm(x; gamma, beta) W^T + bias  given dy: the input-gradient GEMM and the LayerNorm backward in
+    ONE kernel when the row-complete kernel covers the shape (d(LayerNorm output) then never exists in HBM).
+    Returns (dx fp32 = dx_in + ..., dx_lp | None, dgamma, dbeta, dW, dbias) - gradients are None when accumulated in place."""
+    want_lp = want_lp and not rt.exact
+    wt, layout = rt.weight_t(w)
+    if layout == B_NK and _row_kernel_ok(rt, dy.shape[0], wt.shape[0], dy.shape[1], dy.dtype, dy, x, dx_in, dx_out):
+        gg, gb = _gtarget(rt, gamma), _gtarget(rt, beta)
+        direct = gg is not None and gb is not None
+        dx, dx_lp, dg, db = ops.linear_layernorm_bwd(dy, wt, x, gamma, mean, rstd, dx_in=dx_in, dx_out=dx_out, want_lp=want_lp,
+                                                     dgamma=gg if direct else None, dbeta=gb if direct else None)
+        if direct:
+            dg = db = None
+    else:
+        dh = ops.gemm(dy, wt, b_layout=layout)
+        dx, dx_lp, dg, db = _ln_bwd(rt, dh, x, gamma, beta, mean, rstd, dx_in=dx_in, dx_out=dx_out, want_lp=want_lp)
+    dw, dbias = _weight_grads(rt, dy, h_saved, w, bias)
+    return dx, dx_lp, dg, db, dw, dbias
+
+
 def _keep_attention(rt, key, q, k):
     """KEEP_ATTN slow path (vision_transformer.py:67-75,188-195; consumer: scripts/visualise_attentions.py): materialise
     softmax(q k^T * scale) [B, h, Nq, Nk] with plain PyTorch ops, beside the fused kernels that never form it."""
@@ -230,8 +297,10 @@ def _fused_mlp_rows(rt, x, w1, grad):
     return min(tiles * FUSED_MLP_TILE, x.shape[0])
 
 
-def _mlp_fwd(rt, x, g, b, w1, b1, w2, b2, grad=True):
-    rows = _fused_mlp_rows(rt, x, w1, grad)
+def _mlp_fwd(rt, x, g, b, w1, b1, w2, b2, grad=True, ln=None, next_ln=None):
+    """x + fc2(gelu(fc1(LayerNorm(x)))).  ``ln`` = (h, mean, rstd) when the LayerNorm was already produced by the kernel that
+    wrote x; ``next_ln`` = (gamma, beta) of the LayerNorm that follows on the output.  Returns (y, saved | None, next | None)."""
+    rows = _fused_mlp_rows(rt, x, w1, grad) if ln is None else 0
     if rows:
         y = torch.empty_like(x)
         ops.mlp_fwd(x[:rows], g, b, rt.weight(w1), b1, rt.weight(w2), b2, LN_EPS, save=False, out=(y[:rows], None, None, None, None, None))
@@ -240,35 +309,35 @@ def _mlp_fwd(rt, x, g, b, w1, b1, w2, b2, grad=True):
             ht, _, _ = ops.layernorm_fwd(xt, g, b, LN_EPS, rt.act_dtype)
             _, ut = ops.gemm(ht, rt.weight(w1), epilogue=EPI_GELU_GRAD, bias=b1)
             ops.gemm(ut, rt.weight(w2), epilogue=EPI_RESIDUAL, bias=b2, residual=xt, out=y[rows:])
-        return y, None
-    h, mean, rstd = ops.layernorm_fwd(x, g, b, LN_EPS, rt.act_dtype)
+        nxt = ops.layernorm_fwd(y, next_ln[0], next_ln[1], LN_EPS, rt.act_dtype) if next_ln is not None else None
+        return y, None, nxt
+    h, mean, rstd = ln if ln is not None else ops.layernorm_fwd(x, g, b, LN_EPS, rt.act_dtype)
     # fc1 saves gelu'(z) and gelu(z) (one exponential serves both): the backward of the activation is then one multiply
     gd, u = ops.gemm(h, rt.weight(w1), epilogue=EPI_GELU_GRAD, bias=b1)
-    y = ops.gemm(u, rt.weight(w2), epilogue=EPI_RESIDUAL, bias=b2, residual=x)
-    return y, (mean, rstd, h, gd, u)
+    y, nxt = _res_linear(rt, u, w2, b2, x, next_ln)
+    return y, (mean, rstd, h, gd, u), nxt
 
 
 def _mlp_bwd(rt, dy, dy_lp, x, g, b, w1, b1, w2, b2, saved):
     mean, rstd, h, gd, u = saved
     dz, dw2, db2 = _linear_bwd(rt, dy_lp, u, w2, b2, aux=gd)
-    dh, dw1, db1 = _linear_bwd(rt, dz, h, w1, b1)
-    dx, dx_lp, dg, db = _ln_bwd(rt, dh, x, g, b, mean, rstd, dx_in=dy, want_lp=not rt.exact)
+    dx, dx_lp, dg, db, dw1, db1 = _linear_ln_bwd(rt, dz, h, w1, b1, x, g, b, mean, rstd, dx_in=dy)
     return dx, (dx if rt.exact else dx_lp), (dg, db, dw1, db1, dw2, db2)
 
 
-def _attn_branch_fwd(rt, x, g, b, wqkv, bqkv, wproj, bproj, batch, n, key=None):
-    h, mean, rstd = ops.layernorm_fwd(x, g, b, LN_EPS, rt.act_dtype)
+def _attn_branch_fwd(rt, x, g, b, wqkv, bqkv, wproj, bproj, batch, n, key=None, ln=None, next_ln=None):
+    """x + proj(attention(qkv(LayerNorm(x)))); ``ln`` / ``next_ln`` as in _mlp_fwd.  Returns (y, saved, next | None)."""
+    h, mean, rstd = ln if ln is not None else ops.layernorm_fwd(x, g, b, LN_EPS, rt.act_dtype)
     qkv, o, lse = _self_attn_fwd(rt, h, wqkv, bqkv, batch, n, key)
-    y = ops.gemm(o, rt.weight(wproj), epilogue=EPI_RESIDUAL, bias=bproj, residual=x)
-    return y, (mean, rstd, h, qkv, o, lse)
+    y, nxt = _res_linear(rt, o, wproj, bproj, x, next_ln)
+    return y, (mean, rstd, h, qkv, o, lse), nxt
 
 
 def _attn_branch_bwd(rt, dy, dy_lp, x, g, b, wqkv, bqkv, wproj, bproj, saved, batch, n, key=None):
     mean, rstd, h, qkv, o, lse = saved
     do, dwp, dbp = _linear_bwd(rt, dy_lp, o, wproj, bproj)
     dqkv = _self_attn_bwd(rt, do, qkv, o, lse, batch, n, key)
-    dh, dwq, dbq = _linear_bwd(rt, dqkv, h, wqkv, bqkv)
-    dx, dx_lp, dg, db = _ln_bwd(rt, dh, x, g, b, mean, rstd, dx_in=dy, want_lp=not rt.exact)
+    dx, dx_lp, dg, db, dwq, dbq = _linear_ln_bwd(rt, dqkv, h, wqkv, bqkv, x, g, b, mean, rstd, dx_in=dy)
     return dx, (dx if rt.exact else dx_lp), (dg, db, dwq, dbq, dwp, dbp)
 
 
@@ -318,10 +387,15 @@ class EncoderFn(torch.autograd.Function):
         grad = any(ctx.needs_input_grad)  # False under no_grad: nothing is saved for inference
         x, patches, batch, n = _patch_tokens_fwd(rt, img, pw, pb, pos, with_cls=False)
         tape = []
-        for P in blocks:
+        ln1 = None          # (h, mean, rstd) of this block's norm1 when the previous block's fc2 kernel already produced it
+        for i, P in enumerate(blocks):
             g1, b1, wqkv, bqkv, wproj, bproj, g2, b2, w1, bb1, w2, bb2 = P
-            xa, sa = _attn_branch_fwd(rt, x, g1, b1, wqkv, bqkv, wproj, bproj, batch, n, key=('blocks', len(tape), 'attn'))
-            xb, sm = _mlp_fwd(rt, xa, g2, b2, w1, bb1, w2, bb2, grad)
+            # on the no-grad path the one-kernel MLP does its own LayerNorm: nothing to hand over
+            chain = grad or not _fused_mlp_rows(rt, x, w1, grad)
+            xa, sa, ln2 = _attn_branch_fwd(rt, x, g1, b1, wqkv, bqkv, wproj, bproj, batch, n, key=('blocks', i, 'attn'), ln=ln1,
+                                           next_ln=(g2, b2) if chain else None)
+            nxt = (blocks[i + 1][0], blocks[i + 1][1]) if (chain and i + 1 < rt.depth) else None
+            xb, sm, ln1 = _mlp_fwd(rt, xa, g2, b2, w1, bb1, w2, bb2, grad, ln=ln2, next_ln=nxt)
             if grad:
                 tape.append((x, sa, xa, sm))
             x = xb
@@ -378,9 +452,8 @@ def image2_tokens(rt: Runtime, img, pw, pb, pos, cls, block0=None):
     if block0 is None or (rt.cls_tail and rt.c_depth == 1):
         return x.view(batch, rt.n2, rt.dim), None
     g1, b1, wqkv, bqkv, wproj, bproj, gc, bc, gx, bx, wq, bq = block0[:12]
-    xa, _ = _attn_branch_fwd(rt, x, g1, b1, wqkv, bqkv, wproj, bproj, batch, rt.n2)
-    hq, _, _ = ops.layernorm_fwd(xa, gc, bc, LN_EPS, rt.act_dtype)
-    q = ops.gemm(hq, rt.weight(wq), bias=bq)
+    xa, _, lnq = _attn_branch_fwd(rt, x, g1, b1, wqkv, bqkv, wproj, bproj, batch, rt.n2, next_ln=(gc, bc))
+    q = ops.gemm(lnq[0], rt.weight(wq), bias=bq)
     return xa.view(batch, rt.n2, rt.dim), q.view(batch, rt.n2, rt.dim)
 
 
@@ -410,10 +483,11 @@ def decoder_cached(rt: Runtime, tokens2, j_idx, kvs, i_idx, params, q0=None):
     for l in range(rt.c_depth):
         g1, b1, wqkv, bqkv, wproj, bproj, gc, bc, gx, bx, wq, bq, wkv, bkv, wcp, bcp, g2, b2, w1, bb1, w2, bb2 = params[ns + l * nb: ns + (l + 1) * nb]
         cls_only = rt.cls_tail and l == rt.c_depth - 1          # see _dec_block_fwd: the last block runs on the cls row alone
+        lnq = None
         if l == 0 and q0 is not None:
             xa, nq = x, n                                         # cached: x IS x + attn(norm1(x)) of block 0
         elif not cls_only:
-            xa, _ = _attn_branch_fwd(rt, x, g1, b1, wqkv, bqkv, wproj, bproj, batch, n)
+            xa, _, lnq = _attn_branch_fwd(rt, x, g1, b1, wqkv, bqkv, wproj, bproj, batch, n, next_ln=(gc, bc))
             nq = n
         else:
             h1, _, _ = ops.layernorm_fwd(x, g1, b1, LN_EPS, rt.act_dtype)
@@ -424,12 +498,12 @@ def decoder_cached(rt: Runtime, tokens2, j_idx, kvs, i_idx, params, q0=None):
         if l == 0 and q0 is not None:
             q = q0.index_select(0, j_idx)
         else:
-            hq, _, _ = ops.layernorm_fwd(xa, gc, bc, LN_EPS, rt.act_dtype)
+            hq = lnq[0] if lnq is not None else ops.layernorm_fwd(xa, gc, bc, LN_EPS, rt.act_dtype)[0]
             q = ops.gemm(hq, rt.weight(wq), bias=bq)
         kv3 = kvs[l]
         oc, _ = ops.attention_fwd(q.view(batch, nq, d), kv3[:, :, 0:d], kv3[:, :, d:2 * d], rt.heads, rt.scale, kv_index=i_idx)
         xb = ops.gemm(oc.view(batch * nq, d), rt.weight(wcp), epilogue=EPI_RESIDUAL, bias=bcp, residual=xa)
-        x, _ = _mlp_fwd(rt, xb, g2, b2, w1, bb1, w2, bb2, grad=False)
+        x, _, _ = _mlp_fwd(rt, xb, g2, b2, w1, bb1, w2, bb2, grad=False)
     xcls = x if (rt.cls_tail and rt.c_depth > 0) else x.view(batch, n, d)[:, 0, :]
     y, _, _ = ops.layernorm_fwd(xcls, gN, bN, LN_EPS, rt.act_dtype)
     return ops.gemm(y, rt.weight(wh), epilogue=EPI_STORE_F32, bias=bh)
@@ -445,30 +519,32 @@ def _dense_rows(t):
     return out
 
 
-def _dec_block_fwd(rt, x, ctxf, P, batch, n, grad, cls_only, index=0):
+def _dec_block_fwd(rt, x, ctxf, P, batch, n, grad, cls_only, index=0, ln1=None, next_ln=None):
     """One CrossBlock forward (vision_transformer.py:268-272).  ``cls_only`` (the LAST decoder block): only x[:, 0] of the
     block's output reaches the head (:400, :417 - the final norm and the head are row-wise), and within a CrossBlock the
     token rows only mix in the self-attention, as keys / values.  So after the block's qkv projection everything runs on the
     cls row alone: self-attention for query 0, proj, the whole cross-attention query side and the MLP - 1 row instead of
     N2 = 65 / 1025 per pair - with identical logits and identical gradients (the dropped rows' outputs are dead, their
-    gradients exactly zero).  Returns (block output, tape entry)."""
+    gradients exactly zero).  ``ln1`` = (h, mean, rstd) of this block's norm1 when the previous block's fc2 kernel produced it;
+    ``next_ln`` = (gamma, beta) of the NEXT block's norm1.  Returns (block output, tape entry, next block's ln1 | None)."""
     g1, b1, wqkv, bqkv, wproj, bproj, gc, bc, gx, bx, wq, bq, wkv, bkv, wcp, bcp, g2, b2, w1, bb1, w2, bb2 = P
     d = rt.dim
     if not cls_only:
-        xa, sa = _attn_branch_fwd(rt, x, g1, b1, wqkv, bqkv, wproj, bproj, batch, n, key=('cross_blocks', index, 'attn'))
+        xa, sa, lnq = _attn_branch_fwd(rt, x, g1, b1, wqkv, bqkv, wproj, bproj, batch, n, key=('cross_blocks', index, 'attn'), ln=ln1,
+                                       next_ln=(gc, bc))
         nq = n
     else:
-        h1, m1, r1 = ops.layernorm_fwd(x, g1, b1, LN_EPS, rt.act_dtype)
+        h1, m1, r1 = ln1 if ln1 is not None else ops.layernorm_fwd(x, g1, b1, LN_EPS, rt.act_dtype)
         qkv = ops.gemm(h1, rt.weight(wqkv), bias=bqkv)            # K and V of every row feed query 0
         qkv3 = qkv.view(batch, n, 3 * d)
         o0, lse0 = ops.attention_fwd(qkv3[:, 0:1, 0:d], qkv3[:, :, d:2 * d], qkv3[:, :, 2 * d:3 * d], rt.heads, rt.scale)
         o0 = o0.view(batch, d)
         x0 = _dense_rows(x.view(batch, n, d)[:, 0, :])
-        xa = ops.gemm(o0, rt.weight(wproj), epilogue=EPI_RESIDUAL, bias=bproj, residual=x0)
+        xa, lnq = _res_linear(rt, o0, wproj, bproj, x0, (gc, bc))
         sa = (m1, r1, h1, qkv, o0, lse0)
         nq = 1
     # cross attention: q from image-2 tokens, k/v from image-1 features (:174-200)
-    hq, mq, rq = ops.layernorm_fwd(xa, gc, bc, LN_EPS, rt.act_dtype)
+    hq, mq, rq = lnq
     hc, mc, rc = ops.layernorm_fwd(ctxf, gx, bx, LN_EPS, rt.act_dtype)
     q = ops.gemm(hq, rt.weight(wq), bias=bq)
     kv = ops.gemm(hc, rt.weight(wkv), bias=bkv)                      # [Mc, 2D], columns [2][h][hd] (:178)
@@ -477,10 +553,11 @@ def _dec_block_fwd(rt, x, ctxf, P, batch, n, grad, cls_only, index=0):
     if rt.keep_attn:
         _keep_attention(rt, ('cross_blocks', index, 'cross_attn'), q.view(batch, nq, d), kv3[:, :, 0:d])
     oc = oc.view(batch * nq, d)
-    xb = ops.gemm(oc, rt.weight(wcp), epilogue=EPI_RESIDUAL, bias=bcp, residual=xa)
-    xc, sm = _mlp_fwd(rt, xb, g2, b2, w1, bb1, w2, bb2, grad)
+    chain = grad or not _fused_mlp_rows(rt, xa, w1, grad)      # the no-grad one-kernel MLP does its own LayerNorm
+    xb, ln2 = _res_linear(rt, oc, wcp, bcp, xa, (g2, b2) if chain else None)
+    xc, sm, nxt = _mlp_fwd(rt, xb, g2, b2, w1, bb1, w2, bb2, grad, ln=ln2, next_ln=next_ln)
     entry = (x, sa, xa, (mq, rq, hq, mc, rc, hc, q, kv, oc, lse_c), xb, sm) if grad else None
-    return xc, entry
+    return xc, entry, nxt
 
 
 def _dec_block_bwd(rt, dx, dx_lp, ctxf, dctx, P, entry, batch, n, cls_only, tap_index):
@@ -506,13 +583,12 @@ def _dec_block_bwd(rt, dx, dx_lp, ctxf, dctx, P, entry, batch, n, cls_only, tap_
         i = tap_index
         rt.tap[f'dec.doc.{i}'], rt.tap[f'dec.dq.{i}'], rt.tap[f'dec.dkv.{i}'] = doc.clone(), dq.clone(), dkv.clone()
         rt.tap[f'dec.q.{i}'], rt.tap[f'dec.kv.{i}'], rt.tap[f'dec.oc.{i}'] = q.clone(), kv.clone(), oc.clone()
-    dhq, dwq, dbq = _linear_bwd(rt, dq, hq, wq, bq)
-    dhc, dwkv, dbkv = _linear_bwd(rt, dkv, hc, wkv, bkv)
-    dx, dx_lp, dgc, dbc = _ln_bwd(rt, dhq, xa, gc, bc, mq, rq, dx_in=dx, want_lp=not rt.exact)
+    # q = Linear(norm_cross(x')), kv = Linear(norm_context(features)): input-gradient GEMM + LayerNorm backward fused
+    dx, dx_lp, dgc, dbc, dwq, dbq = _linear_ln_bwd(rt, dq, hq, wq, bq, xa, gc, bc, mq, rq, dx_in=dx)
     if rt.exact:
         dx_lp = dx
     # d(context) accumulates over the c_depth blocks in fp32, in place
-    dctx, _, dgx, dbx = _ln_bwd(rt, dhc, ctxf, gx, bx, mc, rc, dx_in=dctx, dx_out=dctx)
+    dctx, _, dgx, dbx, dwkv, dbkv = _linear_ln_bwd(rt, dkv, hc, wkv, bkv, ctxf, gx, bx, mc, rc, dx_in=dctx, dx_out=dctx, want_lp=False)
     if not cls_only:
         dx, dx_lp, (dg1, db1, dwqkv, dbqkv, dwp, dbp) = _attn_branch_bwd(rt, dx, dx_lp, x, g1, b1, wqkv, bqkv, wproj, bproj, sa, batch, n,
                                                                            key=('cross_blocks', tap_index, 'attn'))
@@ -524,10 +600,9 @@ def _dec_block_bwd(rt, dx, dx_lp, ctxf, dctx, P, entry, batch, n, cls_only, tap_
         dqkv3 = dqkv.view(batch, n, 3 * d)
         ops.attention_bwd(qkv3[:, 0:1, 0:d], qkv3[:, :, d:2 * d], qkv3[:, :, 2 * d:3 * d], o0.view(batch, 1, d), do0.view(batch, 1, d),
                           lse0, rt.heads, rt.scale, dqkv3[:, 0:1, 0:d], dqkv3[:, :, d:2 * d], dqkv3[:, :, 2 * d:3 * d])
-        dh1, dwqkv, dbqkv = _linear_bwd(rt, dqkv, h1, wqkv, bqkv)
         dres = torch.zeros((batch * n, d), dtype=torch.float32, device=dx.device)   # the residual path carries gradient on the cls rows only
         dres.view(batch, n, d)[:, 0, :].copy_(dx)
-        dx, dx_lp, dg1, db1 = _ln_bwd(rt, dh1, x, g1, b1, m1, r1, dx_in=dres, want_lp=not rt.exact)
+        dx, dx_lp, dg1, db1, dwqkv, dbqkv = _linear_ln_bwd(rt, dqkv, h1, wqkv, bqkv, x, g1, b1, m1, r1, dx_in=dres)
         if rt.exact:
             dx_lp = dx
     return dx, dx_lp, dctx, [dg1, db1, dwqkv, dbqkv, dwp, dbp, dgc, dbc, dgx, dbx, dwq, dbq, dwkv, dbkv, dwcp, dbcp,
@@ -548,8 +623,10 @@ class DecoderFn(torch.autograd.Function):
         tape = []
         d = rt.dim
         cls_tail = rt.cls_tail and rt.c_depth > 0 and not rt.keep_attn    # the visualisation path wants every query row's map
+        ln1 = None
         for i, P in enumerate(blocks):
-            x, entry = _dec_block_fwd(rt, x, ctxf, P, batch, n, grad, cls_tail and i == rt.c_depth - 1, index=i)
+            nxt = (blocks[i + 1][0], blocks[i + 1][1]) if i + 1 < rt.c_depth else None     # the next block's norm1
+            x, entry, ln1 = _dec_block_fwd(rt, x, ctxf, P, batch, n, grad, cls_tail and i == rt.c_depth - 1, index=i, ln1=ln1, next_ln=nxt)
             if grad:
                 tape.append(entry)
             if rt.tap is not None:

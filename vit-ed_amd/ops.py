@@ -305,6 +305,62 @@ def linear_bwd_weight(dy: torch.Tensor, x: torch.Tensor, want_bias: bool = True,
 
 
 # ---------------------------------------------------------------------------------------------
+def linear_layernorm_supported(m: int, n: int, k: int, dtype: torch.dtype) -> bool:
+    """Whether the row-complete fused Linear + LayerNorm kernels (gemm_row.hip) cover the shape."""
+    return dtype == torch.bfloat16 and bool(_lib.load().vited_linear_layernorm_supported(int(m), int(n), int(k)))
+
+
+def linear_residual_layernorm_fwd(a, w, bias, residual, gamma=None, beta=None, eps: float = 1e-6, out=None):
+    """y = residual + a w^T + bias (fp32) and, with gamma / beta, h = LayerNorm(y) (bf16), mean, rstd - one kernel
+    (``vited_linear_residual_layernorm_fwd``).  Returns (y, h | None, mean | None, rstd | None)."""
+    _need_gpu(a, w, bias, residual, gamma, beta, out)
+    assert a.dtype == w.dtype == torch.bfloat16 and residual.dtype == torch.float32
+    lda, ldw, ldr = _rows2d(a), _rows2d(w), _rows2d(residual)
+    m, k = a.shape
+    n = w.shape[0]
+    assert w.shape[1] == k and residual.shape == (m, n)
+    y = out if out is not None else torch.empty((m, n), dtype=torch.float32, device=a.device)
+    assert y.dtype == torch.float32 and y.shape == (m, n)
+    h = mean = rstd = None
+    if gamma is not None:
+        h = torch.empty((m, n), dtype=torch.bfloat16, device=a.device)
+        mean = torch.empty(m, dtype=torch.float32, device=a.device)
+        rstd = torch.empty(m, dtype=torch.float32, device=a.device)
+    _lib.check(_lib.load().vited_linear_residual_layernorm_fwd(
+        _ptr(a), lda, _ptr(w), ldw, _ptr(bias), _ptr(residual), ldr, _ptr(y), _rows2d(y), _ptr(gamma), _ptr(beta), float(eps),
+        _ptr(h), n, _ptr(mean), _ptr(rstd), m, n, k, _stream()), 'vited_linear_residual_layernorm_fwd')
+    return y, h, mean, rstd
+
+
+def linear_layernorm_bwd(dy, wt, x, gamma, mean, rstd, dx_in=None, dx_out=None, want_lp: bool = False, dgamma=None, dbeta=None):
+    """dx = (dx_in or 0) + LN'(dy wt^T; x, mean, rstd, gamma) in one kernel (``vited_linear_layernorm_bwd``): the input
+    gradient of ``y = LayerNorm(x) W^T`` without materialising d(LayerNorm output).  ``wt`` = the transposed weight shadow
+    [N, K].  Returns (dx fp32, dx_lp bf16 | None, dgamma, dbeta); given ``dgamma`` / ``dbeta`` are ADDED onto."""
+    _need_gpu(dy, wt, x, gamma, mean, rstd, dx_in, dx_out)
+    assert dy.dtype == wt.dtype == torch.bfloat16 and x.dtype == torch.float32
+    lddy, ldwt, ldx = _rows2d(dy), _rows2d(wt), _rows2d(x)
+    m, k = dy.shape
+    n = wt.shape[0]
+    assert wt.shape[1] == k and x.shape == (m, n)
+    lib = _lib.load()
+    if dx_out is None:
+        dx_out = torch.empty((m, n), dtype=torch.float32, device=x.device)
+    dx_lp = torch.empty((m, n), dtype=torch.bfloat16, device=x.device) if want_lp else None
+    accumulate = dgamma is not None
+    if accumulate:
+        assert dbeta is not None and dgamma.dtype == dbeta.dtype == torch.float32 and dgamma.is_contiguous() and dbeta.is_contiguous()
+    else:
+        dgamma = torch.empty(n, dtype=torch.float32, device=x.device)
+        dbeta = torch.empty(n, dtype=torch.float32, device=x.device)
+    ws = workspace(lib.vited_linear_layernorm_bwd_workspace_bytes(m, n), x.device)
+    _lib.check(lib.vited_linear_layernorm_bwd(
+        _ptr(dy), lddy, _ptr(wt), ldwt, _ptr(x), ldx, _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dx_in),
+        _rows2d(dx_in) if dx_in is not None else 0, _ptr(dx_out), _rows2d(dx_out), _ptr(dx_lp), n, _ptr(dgamma), _ptr(dbeta),
+        int(accumulate), m, n, k, _ptr(ws), ws.numel() * 4, _stream()), 'vited_linear_layernorm_bwd')
+    return dx_out, dx_lp, dgamma, dbeta
+
+
+# ---------------------------------------------------------------------------------------------
 def mlp_fused_supported(x: torch.Tensor, w1: torch.Tensor) -> bool:
     """The fused MLP kernel covers bf16, embed dim 384, hidden 1536 (every shipped pjs config)."""
     return w1.dtype == torch.bfloat16 and tuple(w1.shape) == (1536, 384) and x.shape[-1] == 384

@@ -15,6 +15,8 @@ HYPER_HEADER, GROUP_WORDS, DESC_WORDS = 8, 8, 10
 
 
 class FlatAdamW(torch.optim.Optimizer):
+    manages_weight_shadows = True      # functions._install_optimizer_step_hook: this optimizer publishes its updates itself
+
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, model=None):
         """``model`` (the HIP ViT-ED whose parameters these are) lets the kernel refresh the model's bf16 weight shadows in the
         same pass; without it the parameters' version counters are bumped after every update instead, so the model recasts its
