@@ -8,24 +8,34 @@
 //
 // Why: LayerNorm needs whole rows, and the 128 x 128 tile kernels (gemm_mfma.hip) split the 384 columns over three workgroups,
 // so every LayerNorm was its own streaming pass over the fp32 residual stream (196 launches, 4.9 ms of a 30 ms step, round 2).
-// Here one workgroup owns BM complete rows: 4 waves side by side, each BM rows x 96 columns (MT x 6 accumulators of
-// v_mfma_f32_16x16x32_bf16), K-steps of 32 staged by LDS-DMA into the swizzled two-stage image of the other NT kernels
-// (A panel BM x 64 B + the whole W panel 384 x 64 B = 24 KB per step).  Two workgroups per CU (57-59 KB of LDS, <= 256 VGPRs),
-// so one workgroup's HBM-bound epilogue runs under the other's staging-bound main loop.
+// Here one workgroup owns BM complete rows.
+//
+// Main loop = the pipeline of the wide weight-gradient kernel (gemm_tn_wide_kernel): ONE 8-wave workgroup per CU, a 4-slot LDS
+// ring of K = 32 stages (A panel BM x 64 B + the whole W panel 384 x 64 B = 32-33 KB), three stages in flight across a raw
+// s_barrier with counted vmcnt (LDS-DMA from inline asm), the fragments of step t + 1 read under the MFMAs of step t, and the two
+// waves of a SIMD (w, w + 4) taking "issue the next stage's DMA" and "the step's MFMAs" in opposite order.  The W panel is staged
+// once per BM = 128 / 144 rows: 1/96 B per FLOP through the L2 -> LDS path against 1/64 for the 128 x 128 tile.
+// (A first form with 64 / 80-row tiles, two 4-wave workgroups per CU and a two-stage image staged 1/56 B per FLOP with one stage
+// in flight: 500 TF/s in the K loop - slower than the two kernels it replaced for K >= 768.  profiles/README.md, round 3.)
+// Waves sit side by side: wave w owns all BM rows x columns 48 w .. 48 w + 47 (MT x 3 accumulators of v_mfma_f32_16x16x32_bf16).
 //
 // The product is issued transposed (W fragment as the A operand): a lane then holds 4 CONSECUTIVE columns of one row and the
-// tile goes to an fp32 LDS scratch (32 rows x 388 floats, reusing the stage buffers) as 16-byte stores; from there the
+// tile goes to an fp32 LDS scratch (64 or 48 rows x 388 floats per pass, reusing the ring) as 16-byte stores; from there the
 // epilogue is the LayerNorm kernels' own row loop (layernorm.hip): a 32-lane half-wave owns a row, 3 float4 per lane, all global
-// traffic in full lines, row statistics by 5-step butterflies.  dh never reaches HBM and is never rounded to bf16.
+// traffic in full lines, row statistics by 5-step butterflies, the next row's operands in flight under the current row's
+// arithmetic.  dh never reaches HBM and is never rounded to bf16.
 //
-// BM = 64 (MT = 4) or 80 (MT = 5), chosen per M so that the tiles fill the chip's 512 resident slots in the fewest rounds
-// (65,536 rows = 1024 x 64: two full rounds; 66,560 rows = 832 x 80: two rounds, where 1040 x 64 would need three).
+// BM = 128 (MT = 8) or 144 (MT = 9), chosen per M so that the tiles fill the chip's 256 CUs in the fewest rounds
+// (65,536 rows = 512 x 128: two full rounds; 66,560 rows = 463 x 144: two rounds, where 520 x 128 would need three).
+#include <mutex>
+#include <type_traits>
+
 #include "gemm_kernels.h"
 #include "gemm_lds.h"
 
 #define ROW_N 384
 #define ROW_LD 388      // floats per scratch row: 16-byte aligned rows; 388 mod 32 = 4 spreads the 8-lane groups of ds_write_b128 over the banks
-#define ROW_PASS 32     // rows per epilogue pass (scratch = 32 x 388 x 4 = 49,664 B <= the two stages)
+#define RW_STAGES 4     // a power of two: slot = stage & 3
 
 enum { ROW_MODE_FWD = 0, ROW_MODE_BWD = 1 };
 
@@ -45,13 +55,17 @@ struct RowArgs {
 };
 
 template <int MT> struct RowCfg {
+    static_assert(MT == 8 || MT == 9, "tile heights: 128 or 144 rows");
     static constexpr int BM = 16 * MT;
     static constexpr int A_BYTES = BM * 64;
     static constexpr int STAGE_BYTES = A_BYTES + ROW_N * 64;
-    static constexpr int LDS_BYTES = 2 * STAGE_BYTES;
-    static constexpr int NPASS = (BM + ROW_PASS - 1) / ROW_PASS;
-    static_assert(LDS_BYTES >= ROW_PASS * ROW_LD * 4, "epilogue scratch must fit the stage buffers");
-    static_assert(LDS_BYTES >= 8 * 2 * ROW_N * 4, "column-partial combine must fit the stage buffers");
+    static constexpr int LDS_BYTES = RW_STAGES * STAGE_BYTES;            // 131,072 / 135,168
+    static constexpr int PASS_SUB = MT == 8 ? 4 : 3;                     // 16-row sub-tiles per epilogue pass
+    static constexpr int PASS_ROWS = 16 * PASS_SUB;                      // 64 / 48
+    static constexpr int NPASS = MT / PASS_SUB;                          // 2 / 3
+    static constexpr int ROWS_PER_HALF = PASS_ROWS / 16;                 // rows of a pass per half-wave (16 half-waves): 4 / 3
+    static_assert(LDS_BYTES >= PASS_ROWS * ROW_LD * 4, "epilogue scratch must fit the ring");
+    static_assert(LDS_BYTES >= 16 * 2 * ROW_N * 4, "column-partial combine must fit the ring");
 };
 
 __device__ __forceinline__ float row_half_sum(float v) {   // over the 32 lanes of a half-wave
@@ -62,9 +76,10 @@ __device__ __forceinline__ float row_half_sum(float v) {   // over the 32 lanes 
 
 struct RowFwdIn { f32x4 res[3]; };
 struct RowBwdIn { f32x4 x[3], din[3]; float mu, rs; };
+template <int MT> struct RowFrags { bf16x8 a[MT], b[3]; };
 
 template <int MODE, int MT>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(512)
 gemm_row_kernel(const RowArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using C = NtCfg<32>;
@@ -73,64 +88,105 @@ gemm_row_kernel(const RowArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t m0 = (int64_t)blockIdx.x * R::BM;
 
-    f32x4 acc[MT][6];
+    f32x4 acc[MT][3];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 3; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // ---- LDS-DMA roles: a piece = 16 rows x 64 B = one wave-instruction.  Wave w stages A piece w (wave 0 also piece 4 when
-    // MT = 5) and W pieces 6 w .. 6 w + 5.  Lane (rsub, cp) lands at row rsub, 16-byte slot cp, and fetches source chunk
-    // cp ^ swz(row): the swizzle only depends on (row >> 2) & 3 = (rsub >> 2) & 3 for every piece.
+    // ---- LDS-DMA roles: a piece = 16 rows x 64 B = one wave-instruction.  Wave w stages A piece w (wave 0 also piece 8 when
+    // MT = 9) and W pieces 3 w .. 3 w + 2 (its own 48 columns).  Lane (rsub, cp) lands at row rsub, 16-byte slot cp, and fetches
+    // source chunk cp ^ swz(row): the swizzle only depends on (row >> 2) & 3 = (rsub >> 2) & 3 for every piece.
     const int rsub = lane >> 2, cp = lane & 3;
     const int csrc = (cp ^ C::swz(rsub)) * 8;
     int64_t ar = m0 + wave * 16 + rsub;
-    ar = ar < a.M ? ar : a.M - 1;
+    ar = ar < a.M ? ar : a.M - 1;            // rows past M are staged from the last row and never stored
     const bf16* pa = a.A + ar * a.lda + csrc;
-    const bf16* pa4 = pa;
-    if (MT == 5) {
-        int64_t ar4 = m0 + 64 + rsub;
-        ar4 = ar4 < a.M ? ar4 : a.M - 1;
-        pa4 = a.A + ar4 * a.lda + csrc;
+    const bf16* pa8 = pa;
+    if (MT == 9) {
+        int64_t ar8 = m0 + 128 + rsub;
+        ar8 = ar8 < a.M ? ar8 : a.M - 1;
+        pa8 = a.A + ar8 * a.lda + csrc;
     }
-    const bf16* pb = a.W + (int64_t)(wave * 96 + rsub) * a.ldw + csrc;
+    const bf16* pb = a.W + (int64_t)(wave * 48 + rsub) * a.ldw + csrc;
     const int64_t pstep = 16 * a.ldw;
-    auto stage_load = [&](int t, char* stage) {
-        const int k0 = t * 32;
-        glds16(pa + k0, stage + wave * 1024);
-        if (MT == 5 && wave == 0) glds16(pa4 + k0, stage + 4 * 1024);
+    const int nsteps = a.K / 32;
+    auto issue = [&](int stage_idx) {
+        char* dst = smem + (stage_idx & (RW_STAGES - 1)) * R::STAGE_BYTES;
+        const int k0 = stage_idx * 32;
+        glds16_asm(pa + k0, dst + wave * 1024);
+        if (MT == 9 && wave == 0) glds16_asm(pa8 + k0, dst + 8 * 1024);
 #pragma unroll
-        for (int i = 0; i < 6; ++i) glds16(pb + i * pstep + k0, stage + R::A_BYTES + (wave * 6 + i) * 1024);
+        for (int i = 0; i < 3; ++i) glds16_asm(pb + i * pstep + k0, dst + R::A_BYTES + (wave * 3 + i) * 1024);
     };
 
-    // ---- fragment offsets: row (16 i + fr) / (96 wave + 16 j + fr), k-chunk fq; the swizzle again depends on fr only
+    // ---- fragment offsets: row (16 i + fr) / (48 wave + 16 j + fr), k-chunk fq; the swizzle again depends on fr only
     const int fr = lane & 15, fq = lane >> 4;
     const int aoff = C::off(fr, fq);
-    const int boff = R::A_BYTES + wave * 96 * 64 + C::off(fr, fq);
+    const int boff = R::A_BYTES + wave * 48 * 64 + C::off(fr, fq);
+    auto read_frags = [&](RowFrags<MT>& f, const char* st) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) f.a[i] = *(const bf16x8*)(st + aoff + i * 1024);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) f.b[j] = *(const bf16x8*)(st + boff + j * 1024);
+    };
 
-    const int nk = a.K / 32;
-    stage_load(0, smem);
-    for (int t = 0; t < nk; ++t) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();   // stage t landed for every wave; everyone is done reading stage t - 1
-        if (t + 1 < nk) stage_load(t + 1, smem + ((t + 1) & 1) * R::STAGE_BYTES);
-        const char* st = smem + (t & 1) * R::STAGE_BYTES;
-        bf16x8 af[MT], bf_[6];
+    // PER = LDS-DMA instructions per stage of THIS wave (wave-uniform): 4, or 5 for wave 0 of the 144-row tile
+    auto mainloop = [&](auto per_tag) {
+        constexpr int PER = decltype(per_tag)::value;
+        // wait until this wave's pieces of stage `idx` have landed: the stages issued after it stay in flight
+        auto wait_landed = [&](int idx) {
+            const int last = nsteps - 1 < idx + RW_STAGES - 2 ? nsteps - 1 : idx + RW_STAGES - 2;
+            const int later = last - idx;
+            if (later >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
+            else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        };
+        // The barrier of step t certifies stage t + 1 (landed) and frees stage t's slot (every wave holds its stage-t fragments in
+        // registers by then): the fragment reads of step t + 1 are issued UNDER the MFMAs of step t.
+        auto step = [&](int t, const RowFrags<MT>& cur, RowFrags<MT>& nxt) {
+            if (t + 1 < nsteps) wait_landed(t + 1);
+            __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0), as the builtin: hipcc's own bookkeeping then knows the reads retired
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const bool dma_first = wave >= 4;     // waves w and w + 4 share a SIMD: one issues DMA while the other's MFMAs hold the pipe
+            if (dma_first && t + RW_STAGES < nsteps) issue(t + RW_STAGES);     // into the slot stage t has just left
+            if (t + 1 < nsteps) read_frags(nxt, smem + ((t + 1) & (RW_STAGES - 1)) * R::STAGE_BYTES);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < MT; ++i) af[i] = *(const bf16x8*)(st + aoff + i * 1024);
+            for (int j = 0; j < 3; ++j)
 #pragma unroll
-        for (int j = 0; j < 6; ++j) bf_[j] = *(const bf16x8*)(st + boff + j * 1024);
+                for (int i = 0; i < MT; ++i)   // transposed product: lane holds row (16 i + fr), columns 48 wave + 16 j + 4 fq + (0..3)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur.b[j], cur.a[i], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!dma_first && t + RW_STAGES < nsteps) issue(t + RW_STAGES);
+        };
 #pragma unroll
-        for (int j = 0; j < 6; ++j)
-#pragma unroll
-            for (int i = 0; i < MT; ++i)   // transposed product: lane holds row (16 i + fr), columns 96 wave + 16 j + 4 fq + (0..3)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf_[j], af[i], acc[i][j], 0, 0, 0);
-    }
+        for (int pre = 0; pre < RW_STAGES; ++pre)
+            if (nsteps > pre) issue(pre);
+        {
+            const int later = nsteps - 1 < RW_STAGES - 1 ? nsteps - 1 : RW_STAGES - 1;
+            if (later >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PER) : "memory");
+            else if (later == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
+            else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+        RowFrags<MT> fa, fb;
+        read_frags(fa, smem);
+        for (int t = 0; t < nsteps; t += 2) {
+            step(t, fa, fb);
+            if (t + 1 < nsteps) step(t + 1, fb, fa);
+        }
+    };
+    if (MT == 9 && wave == 0) mainloop(std::integral_constant<int, 5>{});
+    else mainloop(std::integral_constant<int, 4>{});
 
-    // ---- epilogue: 32 rows per pass through the fp32 scratch, then the LayerNorm row loop (half-wave per row)
+    // ---- epilogue: PASS_ROWS rows per pass through the fp32 scratch, then the LayerNorm row loop (half-wave per row)
     float* sc = (float*)smem;
     const int hl = lane & 31;
-    const int hw = wave * 2 + (lane >> 5);          // half-wave 0..7: rows hw, hw + 8, hw + 16, hw + 24 of a pass
+    const int hw = wave * 2 + (lane >> 5);          // half-wave 0..15: rows hw, hw + 16, ... of a pass
     const float inv_d = 1.0f / ROW_N;
     f32x4 gm[3], bt[3], bs[3];
 #pragma unroll
@@ -146,7 +202,6 @@ gemm_row_kernel(const RowArgs a) {
         dg[j] = f32x4{0.f, 0.f, 0.f, 0.f};
         db[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-
     auto load_fwd = [&](RowFwdIn& in, int64_t m) {
         const bool ok = m < a.M;
 #pragma unroll
@@ -236,8 +291,7 @@ gemm_row_kernel(const RowArgs a) {
 
 #pragma unroll
     for (int p = 0; p < R::NPASS; ++p) {
-        const int rows_here = (R::BM - p * ROW_PASS) < ROW_PASS ? (R::BM - p * ROW_PASS) : ROW_PASS;   // 32 or 16: compile-time after unrolling
-        const int64_t mp = m0 + p * ROW_PASS;
+        const int64_t mp = m0 + p * R::PASS_ROWS;
         RowFwdIn fcur, fnxt;
         RowBwdIn bcur, bnxt;
         // the first row's operands travel under the dump and its two barriers
@@ -245,25 +299,22 @@ gemm_row_kernel(const RowArgs a) {
         else load_bwd(bcur, mp + hw);
         __syncthreads();       // every wave is done with the LDS (main loop's last stage / the previous pass's rows)
 #pragma unroll
-        for (int ii = 0; ii < 2; ++ii) {
-            const int i = 2 * p + ii;
-            if (i < MT) {
+        for (int ii = 0; ii < R::PASS_SUB; ++ii) {
+            const int i = R::PASS_SUB * p + ii;
 #pragma unroll
-                for (int j = 0; j < 6; ++j) *(f32x4*)(sc + (ii * 16 + fr) * ROW_LD + wave * 96 + j * 16 + fq * 4) = acc[i][j];
-            }
+            for (int j = 0; j < 3; ++j) *(f32x4*)(sc + (ii * 16 + fr) * ROW_LD + wave * 48 + j * 16 + fq * 4) = acc[i][j];
         }
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int r = hw + 8 * k;
-            if (8 * k >= rows_here) break;
-            const bool more = 8 * (k + 1) < rows_here;
+        for (int k = 0; k < R::ROWS_PER_HALF; ++k) {
+            const int r = hw + 16 * k;
+            const bool more = k + 1 < R::ROWS_PER_HALF;
             if (MODE == ROW_MODE_FWD) {
-                if (more) load_fwd(fnxt, mp + r + 8);
+                if (more) load_fwd(fnxt, mp + r + 16);
                 row_fwd(fcur, r, mp + r);
                 if (more) fcur = fnxt;
             } else {
-                if (more) load_bwd(bnxt, mp + r + 8);
+                if (more) load_bwd(bnxt, mp + r + 16);
                 row_bwd(bcur, r, mp + r);
                 if (more) bcur = bnxt;
             }
@@ -271,7 +322,7 @@ gemm_row_kernel(const RowArgs a) {
     }
 
     if (MODE == ROW_MODE_BWD) {
-        // the 8 half-waves' column partials -> one [2][384] row per workgroup (summed over workgroups by ln_bwd_finish)
+        // the 16 half-waves' column partials -> one [2][384] row per workgroup (summed over workgroups by ln_bwd_finish)
         __syncthreads();
         float* my = sc + hw * 2 * ROW_N;
 #pragma unroll
@@ -282,10 +333,10 @@ gemm_row_kernel(const RowArgs a) {
         }
         __syncthreads();
         float* out = a.partial + (int64_t)blockIdx.x * 2 * ROW_N;
-        for (int c = threadIdx.x; c < 2 * ROW_N; c += 256) {
+        for (int c = threadIdx.x; c < 2 * ROW_N; c += 512) {
             float s = 0.f;
 #pragma unroll
-            for (int w = 0; w < 8; ++w) s += sc[w * 2 * ROW_N + c];
+            for (int w = 0; w < 16; ++w) s += sc[w * 2 * ROW_N + c];
             out[c] = s;
         }
     }
@@ -293,9 +344,9 @@ gemm_row_kernel(const RowArgs a) {
 
 // ------------------------------------------------------------------------------------------------
 static inline int row_mt(int64_t M) {
-    // rounds of 512 resident workgroups (2 per CU) x rows per tile: the smaller makespan wins
-    const int64_t c4 = ceil_div64(ceil_div64(M, 64), 512) * 64, c5 = ceil_div64(ceil_div64(M, 80), 512) * 80;
-    return c5 < c4 ? 5 : 4;
+    // rounds of 256 workgroups (one per CU) x rows per tile: the smaller makespan wins
+    const int64_t c8 = ceil_div64(ceil_div64(M, 128), 256) * 128, c9 = ceil_div64(ceil_div64(M, 144), 256) * 144;
+    return c9 < c8 ? 9 : 8;
 }
 
 static inline int64_t row_tiles(int64_t M) { return ceil_div64(M, 16 * row_mt(M)); }
@@ -304,13 +355,21 @@ static bool row_shape_ok(int64_t M, int64_t N, int64_t K) { return N == ROW_N &&
 
 extern "C" int vited_linear_layernorm_supported(int64_t M, int64_t N, int64_t K) { return row_shape_ok(M, N, K) ? 1 : 0; }
 
+template <int MODE, int MT>
+static int row_launch_mt(const RowArgs& a, unsigned tiles, hipStream_t s) {
+    auto kernel = gemm_row_kernel<MODE, MT>;
+    static std::once_flag once;          // dynamic LDS above 64 KB needs the opt-in, once per kernel instance
+    static hipError_t status = hipSuccess;
+    std::call_once(once, [&] { status = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RowCfg<MT>::LDS_BYTES); });
+    if (status != hipSuccess) return VITED_ERR_LAUNCH;
+    hipLaunchKernelGGL(kernel, dim3(tiles), dim3(512), RowCfg<MT>::LDS_BYTES, s, a);
+    return vited_check_launch();
+}
+
 template <int MODE>
 static int row_launch(const RowArgs& a, hipStream_t s) {
-    const int mt = row_mt(a.M);
     const unsigned tiles = (unsigned)row_tiles(a.M);
-    if (mt == 5) hipLaunchKernelGGL((gemm_row_kernel<MODE, 5>), dim3(tiles), dim3(256), RowCfg<5>::LDS_BYTES, s, a);
-    else hipLaunchKernelGGL((gemm_row_kernel<MODE, 4>), dim3(tiles), dim3(256), RowCfg<4>::LDS_BYTES, s, a);
-    return vited_check_launch();
+    return row_mt(a.M) == 9 ? row_launch_mt<MODE, 9>(a, tiles, s) : row_launch_mt<MODE, 8>(a, tiles, s);
 }
 
 static inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
