@@ -154,6 +154,19 @@ int vited_linear_bwd_weight(const void* dY, int64_t lddy, const void* X, int64_t
                             int64_t N, int64_t K, float* dW, float* dbias, int accumulate, float* workspace,
                             int64_t workspace_bytes, void* stream);
 
+/* Several weight gradients in ONE launch: the dW / dbias of every Linear of one transformer block (Block / CrossBlock backward,
+ * vision_transformer.py:124-127, 268-272), queued by the caller and flushed together.  Arrays have `count` (<= 8) entries, all
+ * host memory; entry i is the product of vited_linear_bwd_weight with the same meanings (dbias[i] may be null).  Sharing the
+ * chip's workgroup slots between the products cuts the number of row splits - and the fp32 partial slabs - several-fold.
+ * bf16 only, every K a multiple of 384 and every M >= 4096 (vited_linear_bwd_weight_batched_supported); otherwise the caller
+ * issues vited_linear_bwd_weight per product. */
+int vited_linear_bwd_weight_batched_supported(int count, const int64_t* M, const int64_t* N, const int64_t* K, int dtype);
+int64_t vited_linear_bwd_weight_batched_workspace_bytes(int count, const int64_t* M, const int64_t* N, const int64_t* K);
+int vited_linear_bwd_weight_batched(int count, const void* const* dY, const int64_t* lddy, const void* const* X,
+                                    const int64_t* ldx, const int64_t* M, const int64_t* N, const int64_t* K, float* const* dW,
+                                    float* const* dbias, int dtype, int accumulate, float* workspace, int64_t workspace_bytes,
+                                    void* stream);
+
 /* ---- Linear fused with the LayerNorm on the other side of it (row-complete 384-wide tile, bf16 MFMA; gemm_row.hip) ----
  * The reference's blocks are chains  x = x + f(norm(x))  (Block.forward vision_transformer.py:124-127, CrossBlock.forward
  * :268-272, norm_layer :348): every residual Linear (attn.proj :38, cross_attn.proj :156, timm Mlp fc2) is followed by the next

@@ -345,6 +345,41 @@ def test_linear_bwd_weight(vited, gpu, dtype, M, N, K):
     assert torch.equal(dw, dw2) and torch.equal(db, db2)  # deterministic (slabs, no atomics)
 
 
+@pytest.mark.parametrize('accumulate', [False, True])
+def test_linear_bwd_weight_batched(vited, gpu, accumulate):
+    """The weight gradients of one transformer block in ONE launch (vited_linear_bwd_weight_batched): the seven products of a
+    decoder block at 65-token batches - different N, K, row counts (the kv projection sees the 64-token context) and a strided
+    operand - against fp64 on the same bf16-rounded operands, overwriting and accumulating; and the refusal of sets the wide
+    kernel does not cover."""
+    ops = vited.ops
+    m2, m1 = 65 * 80, 64 * 80           # 5,200 / 5,120 rows
+    shapes = [(m2, 1152, 384, True), (m2, 384, 384, True), (m2, 384, 384, True), (m1, 768, 384, True), (m2, 384, 384, False),
+              (m2, 1536, 384, True), (m2, 384, 1536, True)]
+    items, refs = [], []
+    for i, (m, n, k, bias) in enumerate(shapes):
+        dy = _rand((m, n), gpu, 100 + i, 1.0, torch.bfloat16)
+        if i == 1:                      # a column slice of a wider tensor: row stride != N
+            wide = _rand((m, 2 * n), gpu, 200 + i, 1.0, torch.bfloat16)
+            dy = wide[:, n:]
+        x = _rand((m, k), gpu, 300 + i, 1.0, torch.bfloat16)
+        dw = torch.full((n, k), 0.5 if accumulate else float('nan'), device=gpu)
+        db = torch.full((n,), -0.25 if accumulate else float('nan'), device=gpu) if bias else None
+        items.append((dy, x, dw, db))
+        refs.append((dy.double().t() @ x.double(), dy.double().sum(0)))
+    assert ops.linear_bwd_weight_batched(items, accumulate)
+    for (dy, x, dw, db), (rw, rb) in zip(items, refs):
+        base_w, base_b = (0.5, -0.25) if accumulate else (0.0, 0.0)
+        torch.testing.assert_close(dw.double(), rw + base_w, rtol=2e-4, atol=2e-3 * (x.shape[0] / 4096) ** 0.5)
+        if db is not None:
+            torch.testing.assert_close(db.double(), rb + base_b, rtol=2e-4, atol=2e-3)
+    # not covered: K not a multiple of 384, too few rows, or an fp32 operand -> nothing is launched
+    small = (_rand((512, 384), gpu, 1, 1.0, torch.bfloat16), _rand((512, 384), gpu, 2, 1.0, torch.bfloat16), torch.zeros(384, 384, device=gpu), None)
+    assert not ops.linear_bwd_weight_batched([items[0], small], accumulate)
+    odd = (_rand((m2, 384), gpu, 3, 1.0, torch.bfloat16), _rand((m2, 192), gpu, 4, 1.0, torch.bfloat16), torch.zeros(384, 192, device=gpu), None)
+    assert not ops.linear_bwd_weight_batched([items[0], odd], accumulate)
+    assert not ops.linear_bwd_weight_batched(items + items[:2], accumulate)      # more than 8 products
+
+
 def test_linear_bwd_weight_wide_strided_operands(vited, gpu):
     """dW of the wide tile from column views of wider buffers (the fused qkv gradient / hidden activations are read in place)."""
     ops = vited.ops

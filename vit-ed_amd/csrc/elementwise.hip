@@ -413,6 +413,73 @@ int sum_rows_f32_single_pass(const float* in, int64_t in_ld, float* out, int64_t
     return vited_check_launch();
 }
 
+// The slabs of a batched weight-gradient launch (gemm_tn_batch): one split's block = the products' [N, K] slabs back to back
+// (slab_stride floats), bias sums likewise (bias_stride floats).  One launch sums every product's slabs onto ITS dW / dbias:
+// a thread owns 4 consecutive floats of the concatenated width (every product's width is a multiple of 4).
+#define SB_MAX 8
+struct SumBatch {
+    float* out[2 * SB_MAX];        // dW of product i, then dbias of product i (null = none)
+    int64_t start[2 * SB_MAX + 1]; // first float of each section in the concatenated space [slabs | bias slabs]
+    const float* slabs;
+    const float* bias_slabs;
+    int64_t slab_stride, bias_stride, splits;
+    int sections, accumulate;
+};
+
+__global__ void __launch_bounds__(256) sum_slabs_batch_kernel(const SumBatch b) {
+    const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (r >= b.start[b.sections]) return;
+    int sec = 0;
+    for (int i = 1; i < b.sections; ++i)
+        if (b.start[i] <= r) sec = i;
+    float* out = b.out[sec];
+    if (!out) return;
+    const bool is_bias = r >= b.slab_stride;
+    const float* in = is_bias ? b.bias_slabs + (r - b.slab_stride) : b.slabs + r;
+    const int64_t ld = is_bias ? b.bias_stride : b.slab_stride;
+    out += r - b.start[sec];
+    f32x4 acc = b.accumulate ? *(const f32x4*)out : f32x4{0.f, 0.f, 0.f, 0.f};
+    int64_t k = 0;
+    for (; k + 4 <= b.splits; k += 4) {
+        const f32x4 v0 = *(const f32x4*)(in + k * ld), v1 = *(const f32x4*)(in + (k + 1) * ld);
+        const f32x4 v2 = *(const f32x4*)(in + (k + 2) * ld), v3 = *(const f32x4*)(in + (k + 3) * ld);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += (v0[e] + v1[e]) + (v2[e] + v3[e]);
+    }
+    for (; k < b.splits; ++k) {
+        const f32x4 v = *(const f32x4*)(in + k * ld);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += v[e];
+    }
+    *(f32x4*)out = acc;
+}
+
+int sum_slabs_batch(int count, const float* slabs, int64_t slab_stride, const float* bias_slabs, int64_t bias_stride, int64_t splits,
+                    const int64_t* widths, float* const* dW, const int64_t* nbias, float* const* dbias, int accumulate, hipStream_t s) {
+    if (count < 1 || count > SB_MAX) return VITED_ERR_BAD_ARG;
+    SumBatch b = {};
+    int64_t off = 0;
+    for (int i = 0; i < count; ++i) {
+        if (widths[i] % 4 || nbias[i] % 4 || ((uintptr_t)dW[i] & 15) || ((uintptr_t)dbias[i] & 15)) return VITED_ERR_UNSUPPORTED;
+        b.out[i] = dW[i];
+        b.start[i] = off;
+        off += widths[i];
+    }
+    if (off != slab_stride) return VITED_ERR_BAD_ARG;
+    for (int i = 0; i < count; ++i) {
+        b.out[count + i] = dbias[i];
+        b.start[count + i] = off;
+        off += nbias[i];
+    }
+    b.start[2 * count] = off;
+    b.sections = 2 * count;
+    b.slabs = slabs; b.bias_slabs = bias_slabs; b.slab_stride = slab_stride; b.bias_stride = bias_stride; b.splits = splits;
+    b.accumulate = accumulate;
+    if (((uintptr_t)slabs | (uintptr_t)bias_slabs) & 15 || slab_stride % 4 || bias_stride % 4) return VITED_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(sum_slabs_batch_kernel, dim3((unsigned)ceil_div64(off, 1024)), dim3(256), 0, s, b);
+    return vited_check_launch();
+}
+
 int sum_slabs_pair(const float* in_a, int64_t ld_a, float* out_a, int64_t width_a, const float* in_b, int64_t ld_b, float* out_b,
                    int64_t width_b, int64_t batch, hipStream_t s, int accumulate) {
     const bool vec = (width_a % 4 == 0) && (ld_a % 4 == 0) && (width_b % 4 == 0) && (ld_b % 4 == 0) &&

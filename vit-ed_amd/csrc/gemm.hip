@@ -102,3 +102,42 @@ extern "C" int vited_linear_bwd_weight(const void* dY, int64_t lddy, const void*
     }
     return rc;
 }
+
+// ---- several weight gradients in one launch ----------------------------------------------------------------------------
+extern "C" int vited_linear_bwd_weight_batched_supported(int count, const int64_t* M, const int64_t* N, const int64_t* K, int dtype) {
+    return dtype == VITED_BF16 && gemm_tn_batch_supported(count, M, N, K) ? 1 : 0;
+}
+
+extern "C" int64_t vited_linear_bwd_weight_batched_workspace_bytes(int count, const int64_t* M, const int64_t* N, const int64_t* K) {
+    if (!gemm_tn_batch_supported(count, M, N, K)) return 0;
+    int64_t splits, ws, bs;
+    gemm_tn_batch_layout(count, M, N, K, &splits, &ws, &bs);
+    return splits * (ws + bs) * (int64_t)sizeof(float) + 256;
+}
+
+extern "C" int vited_linear_bwd_weight_batched(int count, const void* const* dY, const int64_t* lddy, const void* const* X,
+                                               const int64_t* ldx, const int64_t* M, const int64_t* N, const int64_t* K,
+                                               float* const* dW, float* const* dbias, int dtype, int accumulate, float* workspace,
+                                               int64_t workspace_bytes, void* stream) {
+    if (count < 1 || !dY || !lddy || !X || !ldx || !M || !N || !K || !dW || !dbias || !workspace) return VITED_ERR_BAD_ARG;
+    if (dtype != VITED_BF16 || !gemm_tn_batch_supported(count, M, N, K)) return VITED_ERR_UNSUPPORTED;
+    if (workspace_bytes < vited_linear_bwd_weight_batched_workspace_bytes(count, M, N, K)) return VITED_ERR_WORKSPACE;
+    int64_t splits, ws, bs;
+    gemm_tn_batch_layout(count, M, N, K, &splits, &ws, &bs);
+    int has_bias[8];
+    int64_t widths[8], nbias[8];
+    for (int i = 0; i < count; ++i) {
+        if (!dY[i] || !X[i] || !dW[i] || lddy[i] < N[i] || ldx[i] < K[i]) return VITED_ERR_BAD_ARG;
+        has_bias[i] = dbias[i] != nullptr;
+        widths[i] = N[i] * K[i];
+        nbias[i] = N[i];
+    }
+    float* base = (float*)(((uintptr_t)workspace + 15) & ~(uintptr_t)15);
+    float* slabs = base;
+    float* bias_slabs = base + splits * ws;
+    hipStream_t s = (hipStream_t)stream;
+    g_last_gemm_path = 2;
+    int rc = gemm_tn_batch(count, dY, lddy, X, ldx, M, N, K, has_bias, slabs, bias_slabs, s);
+    if (rc != VITED_OK) return rc;
+    return sum_slabs_batch(count, slabs, ws, bias_slabs, bs, splits, widths, dW, nbias, dbias, accumulate, s);
+}

@@ -519,17 +519,48 @@ __device__ __forceinline__ void tw_read_frags(TwFrags& f, const char* st, const 
     }
 }
 
+// One launch may carry several weight-gradient products (the dW of every Linear of one transformer block, queued by
+// functions.py and flushed at the end of the block's backward): the chip's 256 workgroup slots are then shared by ~36-48 output
+// tiles instead of 3-12, so each product is split over 5-7 row ranges instead of 21-85 and writes that many fewer fp32 slabs
+// (round 2: 9 GB of slab traffic per step, as much as the operands for the N = K = 384 products).
+#define TW_MAX_PROBLEMS 8
+struct TwProblem {
+    const bf16* dY;
+    const bf16* X;
+    int64_t lddy, ldx, M, rows_per_split;
+    int64_t slab_off, bias_off;     // float offsets of this product inside ONE split's slab block / bias block
+    int N, K, tiles_k, tile0;       // tile0 = index of its first output tile in the launch
+    int has_bias, pad_;
+};
+struct TwBatch {
+    TwProblem p[TW_MAX_PROBLEMS];
+    int64_t slab_stride, bias_stride;   // floats per split
+    int count, total_tiles;
+};
+
 template <bool BIAS>
 __global__ void __launch_bounds__(512)
-gemm_tn_wide_kernel(const bf16* __restrict__ dY, int64_t lddy, const bf16* __restrict__ X, int64_t ldx, int64_t M, int64_t N,
-                    int64_t K, int64_t rows_per_split, int tiles_k, float* __restrict__ out, float* __restrict__ bias_out) {
+gemm_tn_wide_kernel(const TwBatch batch, float* __restrict__ out_base, float* __restrict__ bias_base) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = wave >> 2, wc = wave & 3;
-    const int ntile = gridDim.x;
+    const int ntile = batch.total_tiles;
     const int lin = xcd_remap(blockIdx.x + blockIdx.y * ntile, ntile * gridDim.y);   // one m-split's tiles share an XCD
-    const int split = lin / ntile, tile_id = lin - split * ntile;
+    const int split = lin / ntile;
+    int tile_id = lin - split * ntile;
+    int pi = 0;
+    for (int i = 1; i < batch.count; ++i)
+        if (batch.p[i].tile0 <= tile_id) pi = i;
+    const TwProblem& pr = batch.p[pi];
+    tile_id -= pr.tile0;
+    const bf16* __restrict__ dY = pr.dY;
+    const bf16* __restrict__ X = pr.X;
+    const int64_t lddy = pr.lddy, ldx = pr.ldx, M = pr.M, N = pr.N, K = pr.K, rows_per_split = pr.rows_per_split;
+    const int tiles_k = pr.tiles_k;
+    const bool with_bias = BIAS && pr.has_bias;
+    float* __restrict__ out = out_base + pr.slab_off;
+    float* __restrict__ bias_out = bias_base + pr.bias_off;
     const int64_t n0 = (int64_t)(tile_id / tiles_k) * 128, kc0 = (int64_t)(tile_id % tiles_k) * 384;
     const int64_t mb = (int64_t)split * rows_per_split;
     int64_t me = mb + rows_per_split;
@@ -659,7 +690,7 @@ gemm_tn_wide_kernel(const bf16* __restrict__ dY, int64_t lddy, const bf16* __res
 #ifndef TW_DBG_NO_DMA
         if (!dma_first && t + TW_STAGES < nsteps) issue(t + TW_STAGES);
 #endif
-        if (BIAS && kc0 == 0) {
+        if (with_bias && kc0 == 0) {
             typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
             const bf16x2_t one2 = {(__bf16)1.0f, (__bf16)1.0f};
 #pragma unroll
@@ -704,7 +735,7 @@ gemm_tn_wide_kernel(const bf16* __restrict__ dY, int64_t lddy, const bf16* __res
         }
     }
 
-    float* o = out + (int64_t)split * N * K;
+    float* o = out + (int64_t)split * batch.slab_stride;
     const int fr = lane & 15, fq = lane >> 4;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -716,8 +747,8 @@ gemm_tn_wide_kernel(const bf16* __restrict__ dY, int64_t lddy, const bf16* __res
         }
     }
     if constexpr (BIAS) {
-        if (kc0 == 0 && wc == 0) {
-            float* bo = bias_out + (int64_t)split * N;
+        if (with_bias && kc0 == 0 && wc == 0) {
+            float* bo = bias_out + (int64_t)split * batch.bias_stride;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 float v = bsum[i];
@@ -815,12 +846,8 @@ static int launch_tn(const void* dY, int64_t lddy, const void* X, int64_t ldx, i
     return VITED_OK;
 }
 
-static int launch_tn_wide(const void* dY, int64_t lddy, const void* X, int64_t ldx, int64_t M, int64_t N, int64_t K, int64_t splits,
-                           float* out, float* bias_out, hipStream_t s) {
+static int launch_tn_wide_batch(const TwBatch& b, int64_t splits, bool any_bias, float* out, float* bias_out, hipStream_t s) {
     constexpr int LDS = TW_STAGES * TW_STAGE_BYTES;
-    const int tiles_k = (int)(K / 384);
-    const int tiles = (int)ceil_div64(N, 128) * tiles_k;
-    const int64_t rps = ceil_div64(ceil_div64(M, splits), 32) * 32;
     static std::once_flag once;
     static hipError_t status = hipSuccess;
     std::call_once(once, [&] {
@@ -829,13 +856,83 @@ static int launch_tn_wide(const void* dY, int64_t lddy, const void* X, int64_t l
             status = hipFuncSetAttribute((const void*)gemm_tn_wide_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     });
     if (status != hipSuccess) return VITED_ERR_LAUNCH;
-    if (bias_out)
-        hipLaunchKernelGGL((gemm_tn_wide_kernel<true>), dim3(tiles, (unsigned)splits), dim3(512), LDS, s, (const bf16*)dY, lddy,
-                           (const bf16*)X, ldx, M, N, K, rps, tiles_k, out, bias_out);
+    if (any_bias)
+        hipLaunchKernelGGL((gemm_tn_wide_kernel<true>), dim3(b.total_tiles, (unsigned)splits), dim3(512), LDS, s, b, out, bias_out);
     else
-        hipLaunchKernelGGL((gemm_tn_wide_kernel<false>), dim3(tiles, (unsigned)splits), dim3(512), LDS, s, (const bf16*)dY, lddy,
-                           (const bf16*)X, ldx, M, N, K, rps, tiles_k, out, bias_out);
+        hipLaunchKernelGGL((gemm_tn_wide_kernel<false>), dim3(b.total_tiles, (unsigned)splits), dim3(512), LDS, s, b, out, bias_out);
     return VITED_OK;
+}
+
+static int launch_tn_wide(const void* dY, int64_t lddy, const void* X, int64_t ldx, int64_t M, int64_t N, int64_t K, int64_t splits,
+                          float* out, float* bias_out, hipStream_t s) {
+    TwBatch b = {};
+    TwProblem& p = b.p[0];
+    p.dY = (const bf16*)dY; p.X = (const bf16*)X; p.lddy = lddy; p.ldx = ldx; p.M = M;
+    p.rows_per_split = ceil_div64(ceil_div64(M, splits), 32) * 32;
+    p.N = (int)N; p.K = (int)K; p.tiles_k = (int)(K / 384); p.tile0 = 0; p.has_bias = bias_out != nullptr;
+    b.count = 1;
+    b.total_tiles = (int)ceil_div64(N, 128) * p.tiles_k;
+    b.slab_stride = N * K;
+    b.bias_stride = N;
+    return launch_tn_wide_batch(b, splits, bias_out != nullptr, out, bias_out, s);
+}
+
+// ---- several products in one launch (see TwBatch) ------------------------------------------------------------------------
+bool gemm_tn_batch_supported(int count, const int64_t* M, const int64_t* N, const int64_t* K) {
+    if (count < 1 || count > TW_MAX_PROBLEMS) return false;
+    for (int i = 0; i < count; ++i)
+        if (!tn_use_wide(M[i], N[i], K[i]) || N[i] % 8 || N[i] > (1 << 20) || K[i] > (1 << 20)) return false;
+    return true;
+}
+
+static inline int64_t tn_batch_splits(int count, const int64_t* M, const int64_t* N, const int64_t* K) {
+    int64_t tiles = 0, mmin = M[0];
+    for (int i = 0; i < count; ++i) {
+        tiles += ceil_div64(N[i], 128) * (K[i] / 384);
+        mmin = M[i] < mmin ? M[i] : mmin;
+    }
+    int64_t s = 256 / tiles;                      // one workgroup per CU, one round
+    const int64_t max_s = ceil_div64(mmin, 256);
+    if (s > max_s) s = max_s;
+    return s < 1 ? 1 : s;
+}
+
+void gemm_tn_batch_layout(int count, const int64_t* M, const int64_t* N, const int64_t* K, int64_t* splits, int64_t* slab_stride,
+                          int64_t* bias_stride) {
+    *splits = tn_batch_splits(count, M, N, K);
+    int64_t w = 0, b = 0;
+    for (int i = 0; i < count; ++i) {
+        w += N[i] * K[i];
+        b += N[i];
+    }
+    *slab_stride = w;
+    *bias_stride = b;
+}
+
+int gemm_tn_batch(int count, const void* const* dY, const int64_t* lddy, const void* const* X, const int64_t* ldx, const int64_t* M,
+                  const int64_t* N, const int64_t* K, const int* has_bias, float* slabs, float* bias_slabs, hipStream_t s) {
+    TwBatch b = {};
+    int64_t splits;
+    gemm_tn_batch_layout(count, M, N, K, &splits, &b.slab_stride, &b.bias_stride);
+    int tile = 0;
+    int64_t woff = 0, boff = 0;
+    bool any_bias = false;
+    for (int i = 0; i < count; ++i) {
+        TwProblem& p = b.p[i];
+        if (!gemm_tn_mfma_supported(dY[i], lddy[i], X[i], ldx[i], M[i], N[i], K[i])) return VITED_ERR_UNSUPPORTED;
+        p.dY = (const bf16*)dY[i]; p.X = (const bf16*)X[i]; p.lddy = lddy[i]; p.ldx = ldx[i]; p.M = M[i];
+        p.rows_per_split = ceil_div64(ceil_div64(M[i], splits), 32) * 32;
+        p.N = (int)N[i]; p.K = (int)K[i]; p.tiles_k = (int)(K[i] / 384); p.tile0 = tile; p.has_bias = has_bias[i];
+        p.slab_off = woff; p.bias_off = boff;
+        tile += (int)ceil_div64(N[i], 128) * p.tiles_k;
+        woff += N[i] * K[i];
+        boff += N[i];
+        any_bias = any_bias || has_bias[i];
+    }
+    b.count = count;
+    b.total_tiles = tile;
+    const int rc = launch_tn_wide_batch(b, splits, any_bias, slabs, bias_slabs, s);
+    return rc != VITED_OK ? rc : vited_check_launch();
 }
 
 int gemm_tn_mfma(const void* dY, int64_t lddy, const void* X, int64_t ldx, int64_t M, int64_t N, int64_t K, int64_t splits,

@@ -80,7 +80,10 @@ class Runtime:
         self.cls_tail = os.environ.get('VITED_CLS_TAIL', '1') != '0'   # last decoder block on the cls rows only (exact; see _dec_block_fwd)
         self.fused_mlp = os.environ.get('VITED_FUSED_MLP', '1') != '0'   # vited_mlp_fwd on the no-grad paths
         self.fused_ln = os.environ.get('VITED_FUSED_LN', '1') != '0'     # LayerNorm inside the neighbouring Linear's kernel (gemm_row.hip)
+        self.batch_dw = os.environ.get('VITED_BATCH_DW', '1') != '0'     # a block's weight gradients in one launch (vited_linear_bwd_weight_batched)
+        self.dw_queue = None        # inside a block's backward: [(dy, x, dW target, dbias target | None, accumulate)]
         self.tap = None             # test/diagnostic: a dict that receives clones of per-block activations and gradients
+        self.block_events = None    # measurement (bench.py): a list that receives (kind, block, 'fwd' | 'bwd', start event, end event)
         self.pinned = False         # a captured hipGraph reads the shadow buffers: never free one, only refresh in place
         self._retired = []
         self._shadow = {}
@@ -145,6 +148,27 @@ class Runtime:
                 self._shadow[(pid, tag)] = (p._version, p.data_ptr(), buf)
 
 
+class _BlockSpan:
+    """Brackets one block's launches with HIP events on the launch stream when ``rt.block_events`` is a list (bench.py's
+    ``fused_block`` figure: time of the attention + MLP block's kernels); free otherwise."""
+
+    def __init__(self, rt, kind, index, phase):
+        self.sink, self.tag = rt.block_events, (kind, index, phase)
+
+    def __enter__(self):
+        if self.sink is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.sink is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self.sink.append(self.tag + (self.e0, e1))
+        return False
+
+
 def _lp(rt: Runtime, t_f32: torch.Tensor) -> torch.Tensor:
     return t_f32 if rt.exact else ops.cast(t_f32, rt.act_dtype)
 
@@ -173,14 +197,61 @@ def _ln_bwd(rt, dy, x, gamma, beta, mean, rstd, **kw):
 
 
 def _weight_grads(rt, dy, x_saved, w, b):
-    """(dW | None, db | None) of y = x W^T + b; None when accumulated straight into w.grad / b.grad."""
+    """(dW | None, db | None) of y = x W^T + b; None when accumulated straight into w.grad / b.grad.  Inside a _DwBatch (one
+    transformer block's backward) the product is only QUEUED: the block's weight gradients then go out as one launch."""
     gw = _gtarget(rt, w)
     gb = _gtarget(rt, b) if b is not None else None
-    if gw is not None and (b is None or gb is not None):
+    direct = gw is not None and (b is None or gb is not None)
+    q = rt.dw_queue
+    if q is not None and dy.dtype == torch.bfloat16 and dy.shape[0] >= 4096 and x_saved.shape[1] % 384 == 0:
+        if direct:
+            q.append((dy, x_saved, gw.view(gw.shape[0], -1), gb, True))
+            return None, None
+        dw = torch.empty((dy.shape[1], x_saved.shape[1]), dtype=torch.float32, device=dy.device)
+        db = torch.empty(dy.shape[1], dtype=torch.float32, device=dy.device) if b is not None else None
+        q.append((dy, x_saved, dw, db, False))
+        return dw.view_as(w), db
+    if direct:
         ops.linear_bwd_weight(dy, x_saved, want_bias=b is not None, dw_out=gw.view(gw.shape[0], -1), db_out=gb)
         return None, None
     dw, db = ops.linear_bwd_weight(dy, x_saved)
     return dw.view_as(w), (db if b is not None else None)
+
+
+class _DwBatch:
+    """``with _DwBatch(rt):`` around one block's backward: the weight-gradient products issued inside are collected and
+    launched together on exit (vited_linear_bwd_weight_batched) - they only read tensors the block's backward already produced,
+    and nothing inside the block consumes a weight gradient."""
+
+    def __init__(self, rt):
+        self.rt = rt
+
+    def __enter__(self):
+        self.outer = self.rt.dw_queue
+        self.rt.dw_queue = [] if (self.rt.batch_dw and not self.rt.exact) else None
+        return self
+
+    def __exit__(self, exc_type, *exc):
+        q, self.rt.dw_queue = self.rt.dw_queue, self.outer
+        if exc_type is not None or not q:
+            return False
+        for acc in (True, False):
+            group = [(dy, x, dw, db) for dy, x, dw, db, a in q if a == acc]
+            for i in range(0, len(group), ops.MAX_BATCHED_WEIGHT_GRADS):
+                part = group[i: i + ops.MAX_BATCHED_WEIGHT_GRADS]
+                if len(part) > 1 and ops.linear_bwd_weight_batched(part, acc):
+                    continue
+                for dy, x, dw, db in part:
+                    ops.linear_bwd_weight(dy, x, want_bias=db is not None, dw_out=dw, db_out=db) if acc else \
+                        _overwrite_weight_grad(dy, x, dw, db)
+        return False
+
+
+def _overwrite_weight_grad(dy, x, dw, db):
+    got_w, got_b = ops.linear_bwd_weight(dy, x, want_bias=db is not None)
+    dw.copy_(got_w)
+    if db is not None:
+        db.copy_(got_b)
 
 
 def _linear_bwd(rt, dy, x_saved, w, b=None, want_dx=True, aux=None):
@@ -392,10 +463,11 @@ class EncoderFn(torch.autograd.Function):
             g1, b1, wqkv, bqkv, wproj, bproj, g2, b2, w1, bb1, w2, bb2 = P
             # on the no-grad path the one-kernel MLP does its own LayerNorm: nothing to hand over
             chain = grad or not _fused_mlp_rows(rt, x, w1, grad)
-            xa, sa, ln2 = _attn_branch_fwd(rt, x, g1, b1, wqkv, bqkv, wproj, bproj, batch, n, key=('blocks', i, 'attn'), ln=ln1,
-                                           next_ln=(g2, b2) if chain else None)
-            nxt = (blocks[i + 1][0], blocks[i + 1][1]) if (chain and i + 1 < rt.depth) else None
-            xb, sm, ln1 = _mlp_fwd(rt, xa, g2, b2, w1, bb1, w2, bb2, grad, ln=ln2, next_ln=nxt)
+            with _BlockSpan(rt, 'enc', i, 'fwd'):
+                xa, sa, ln2 = _attn_branch_fwd(rt, x, g1, b1, wqkv, bqkv, wproj, bproj, batch, n, key=('blocks', i, 'attn'), ln=ln1,
+                                               next_ln=(g2, b2) if chain else None)
+                nxt = (blocks[i + 1][0], blocks[i + 1][1]) if (chain and i + 1 < rt.depth) else None
+                xb, sm, ln1 = _mlp_fwd(rt, xa, g2, b2, w1, bb1, w2, bb2, grad, ln=ln2, next_ln=nxt)
             if grad:
                 tape.append((x, sa, xa, sm))
             x = xb
@@ -418,9 +490,10 @@ class EncoderFn(torch.autograd.Function):
             g1, b1, wqkv, bqkv, wproj, bproj, g2, b2, w1, bb1, w2, bb2 = params[3 + i * nb: 3 + (i + 1) * nb]
             x, sa, xa, sm = ctx.tape[i]
             ctx.tape[i] = None
-            dx, dx_lp, (dg2, db2, dw1, dbb1, dw2, dbb2) = _mlp_bwd(rt, dx, dx_lp, xa, g2, b2, w1, bb1, w2, bb2, sm)
-            dx, dx_lp, (dg1, db1, dwq, dbq, dwp, dbp) = _attn_branch_bwd(rt, dx, dx_lp, x, g1, b1, wqkv, bqkv, wproj, bproj, sa, batch, n,
-                                                                         key=('blocks', i, 'attn'))
+            with _BlockSpan(rt, 'enc', i, 'bwd'), _DwBatch(rt):
+                dx, dx_lp, (dg2, db2, dw1, dbb1, dw2, dbb2) = _mlp_bwd(rt, dx, dx_lp, xa, g2, b2, w1, bb1, w2, bb2, sm)
+                dx, dx_lp, (dg1, db1, dwq, dbq, dwp, dbp) = _attn_branch_bwd(rt, dx, dx_lp, x, g1, b1, wqkv, bqkv, wproj, bproj, sa, batch, n,
+                                                                             key=('blocks', i, 'attn'))
             if rt.tap is not None:
                 rt.tap[f'enc.dx.{i}'] = dx.clone()      # gradient w.r.t. the INPUT of encoder block i
             base = 3 + i * nb
@@ -675,8 +748,9 @@ class DecoderFn(torch.autograd.Function):
             P = params[ns + i * nb: ns + (i + 1) * nb]
             entry = ctx.tape[i]
             ctx.tape[i] = None
-            dx, dx_lp, dctx, blk = _dec_block_bwd(rt, dx, dx_lp, ctx.ctxf, dctx, P, entry, batch, n,
-                                                  ctx.cls_tail and i == rt.c_depth - 1, i)
+            with _DwBatch(rt):
+                dx, dx_lp, dctx, blk = _dec_block_bwd(rt, dx, dx_lp, ctx.ctxf, dctx, P, entry, batch, n,
+                                                      ctx.cls_tail and i == rt.c_depth - 1, i)
             if rt.tap is not None:
                 rt.tap[f'dec.dx.{i}'] = dx.clone()      # gradient w.r.t. the INPUT of decoder block i
                 rt.tap[f'dec.dctx.{i}'] = dctx.clone()  # running d(features) after blocks c_depth-1 .. i

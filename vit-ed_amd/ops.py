@@ -304,6 +304,43 @@ def linear_bwd_weight(dy: torch.Tensor, x: torch.Tensor, want_bias: bool = True,
     return dw, db
 
 
+MAX_BATCHED_WEIGHT_GRADS = 8
+
+
+def linear_bwd_weight_batched(items, accumulate: bool) -> bool:
+    """items: list of (dy [M, N], x [M, K], dw fp32 [N, K] contiguous, db fp32 [N] | None).  dW_i (+)= dy_i^T x_i and db_i (+)= column
+    sums of dy_i for every item in ONE launch of the wide weight-gradient kernel + one slab-sum launch
+    (``vited_linear_bwd_weight_batched``).  Returns False (nothing launched) when the set is not covered - the caller then issues
+    ``linear_bwd_weight`` per item."""
+    import ctypes as C
+    n = len(items)
+    if n < 1 or n > MAX_BATCHED_WEIGHT_GRADS:
+        return False
+    for dy, x, dw, db in items:
+        _need_gpu(dy, x, dw, db)
+        if dy.dtype != torch.bfloat16 or x.dtype != torch.bfloat16 or dy.shape[0] != x.shape[0]:
+            return False
+        assert dw.dtype == torch.float32 and dw.is_contiguous() and dw.numel() == dy.shape[1] * x.shape[1]
+        assert db is None or (db.dtype == torch.float32 and db.is_contiguous() and db.numel() == dy.shape[1])
+    i64, vp = C.c_int64 * n, C.c_void_p * n
+    M = i64(*[it[0].shape[0] for it in items])
+    N = i64(*[it[0].shape[1] for it in items])
+    K = i64(*[it[1].shape[1] for it in items])
+    lib = _lib.load()
+    if not lib.vited_linear_bwd_weight_batched_supported(n, M, N, K, BF16):
+        return False
+    lddy = i64(*[_rows2d(it[0]) for it in items])
+    ldx = i64(*[_rows2d(it[1]) for it in items])
+    dY = vp(*[it[0].data_ptr() for it in items])
+    X = vp(*[it[1].data_ptr() for it in items])
+    dW = vp(*[it[2].data_ptr() for it in items])
+    dB = vp(*[_ptr(it[3]) or None for it in items])
+    ws = workspace(lib.vited_linear_bwd_weight_batched_workspace_bytes(n, M, N, K), items[0][0].device)
+    _lib.check(lib.vited_linear_bwd_weight_batched(n, dY, lddy, X, ldx, M, N, K, dW, dB, BF16, int(bool(accumulate)), _ptr(ws),
+                                                   ws.numel() * 4, _stream()), 'vited_linear_bwd_weight_batched')
+    return True
+
+
 # ---------------------------------------------------------------------------------------------
 def linear_layernorm_supported(m: int, n: int, k: int, dtype: torch.dtype) -> bool:
     """Whether the row-complete fused Linear + LayerNorm kernels (gemm_row.hip) cover the shape."""
