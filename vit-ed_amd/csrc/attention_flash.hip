@@ -10,8 +10,14 @@
 //             buffered: the next tile's loads are in flight under the current tile's MFMAs); running
 //             max / sum per query, O rescaled per tile; LSE saved.
 //   backward  dQ kernel : the forward loop with S^T, dP^T = V dO^T, dS^T = P^T o (dP^T - delta),
-//                         dQ^T += K^T dS^T (K read transposed from the same LDS image); also writes
-//                         delta = rowsum(dO o O) for the second kernel.
+//                         dQ^T += K^T dS^T (K read transposed from the same LDS image).  delta: the textbook
+//                         rowsum(dO o O) uses the forward's bf16-ROUNDED O, which is inconsistent with the fp32 P o dP it is
+//                         subtracted from - on near-uniform attention (dP ~ delta for every key) that bias dominates dS
+//                         (measured at 1024 keys, 4 + 4 blocks: d(kv) 83 % off where PyTorch's bf16 autocast is 7 % off).
+//                         The loop therefore runs with that estimate, accumulates the EXACT delta = sum_j P o dP of its own
+//                         P and dP beside it (one FMA per score) together with B^T = K^T P^T (one more MFMA product on the
+//                         K^T fragment already loaded), and finishes dQ -= (delta - estimate) * B: algebraically the softmax
+//                         backward with the exact delta, in one pass.  The exact delta is what the second kernel reads.
 //             dKV kernel: one workgroup = 4 waves x 32 keys; loops over 64-query tiles of Q / dO / lse /
 //                         delta; S = Q K^T and dP = dO V^T put the query on accumulator rows, so
 //                         dV^T += dO^T P and dK^T += Q^T dS contract over accumulator rows again.
@@ -262,8 +268,8 @@ attn_bwd_dq_flash_kernel(AttnArgs a) {
     const float sc = a.scale * LOG2E;
 
     bf16x8 qf[FL_W][C::KCH], dof[FL_W][C::KCH];
-    f32x4 dq[FL_W][C::DT];
-    float lse2[FL_W], dl[FL_W];
+    f32x4 dq[FL_W][C::DT], bq[FL_W][C::DT];   // dQ^T with the estimated delta; B^T = K^T P^T for the exact-delta correction
+    float lse2[FL_W], dl[FL_W], dex[FL_W];    // dl: delta estimated from the saved (bf16) O; dex: this lane's part of sum_j P o dP
 #pragma unroll
     for (int w = 0; w < FL_W; ++w) {
         load_row_frags<HD>(qb, a.q_ts, q0 + 16 * w, nq, fr, g, qf[w]);
@@ -276,12 +282,15 @@ attn_bwd_dq_flash_kernel(AttnArgs a) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) d = fmaf((float)of[c][e], (float)dof[w][c][e], d);
         dl[w] = group_sum4(d);
+        dex[w] = 0.f;
         const int q = q0 + 16 * w + fr;
         const int qc = q < nq ? q : nq - 1;
         lse2[w] = a.lse[(b * a.heads + h) * a.nq + qc] * LOG2E;
-        if (g == 0 && q < nq) a.delta[(b * a.heads + h) * a.nq + q] = dl[w];
 #pragma unroll
-        for (int dt = 0; dt < C::DT; ++dt) dq[w][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int dt = 0; dt < C::DT; ++dt) {
+            dq[w][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            bq[w][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
     }
     const int ntiles = (nk + FL_TILE - 1) / FL_TILE;
     bf16x8 kr[F::PASSES], vr[F::PASSES];
@@ -308,8 +317,10 @@ attn_bwd_dq_flash_kernel(AttnArgs a) {
         {   // VALU-bound like the forward loop: same instruction diet
         constexpr bool RAGGED = decltype(ragged_tag)::value;
         f32x4 ds[FL_W][4];
+        bf16x8 pp[FL_W][2];     // the probabilities themselves, packed for the B^T product
 #pragma unroll
         for (int w = 0; w < FL_W; ++w) {
+            f32x4 pk[2];
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
                 f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
@@ -323,17 +334,22 @@ attn_bwd_dq_flash_kernel(AttnArgs a) {
                     float pe = __builtin_amdgcn_exp2f(fmaf(s[e], sc, -lse2[w]));
                     if constexpr (RAGGED) pe = (t * FL_TILE + 16 * kt + 4 * g + e) < nk ? pe : 0.f;
                     ds[w][kt][e] = pe * (dp[e] - dl[w]);
+                    dex[w] = fmaf(pe, dp[e], dex[w]);
+                    pk[kt & 1][e] = pe;
                 }
+                if (kt & 1) pp[w][kt >> 1] = pack_pair(pk[0], pk[1]);
             }
         }
 #pragma unroll
         for (int dt = 0; dt < C::DT; ++dt)
 #pragma unroll
             for (int k2 = 0; k2 < 2; ++k2) {
-                const bf16x8 kt_ = tr_frag<HD>(ks, k2, dt, g, qq, p);   // one transposed K fragment feeds every query tile
+                const bf16x8 kt_ = tr_frag<HD>(ks, k2, dt, g, qq, p);   // one transposed K fragment feeds every query tile, both products
 #pragma unroll
-                for (int w = 0; w < FL_W; ++w)
+                for (int w = 0; w < FL_W; ++w) {
                     dq[w][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt_, pack_pair(ds[w][2 * k2], ds[w][2 * k2 + 1]), dq[w][dt], 0, 0, 0);
+                    bq[w][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt_, pp[w][k2], bq[w][dt], 0, 0, 0);
+                }
             }
         }
         if (t + 1 < ntiles) {
@@ -349,10 +365,18 @@ attn_bwd_dq_flash_kernel(AttnArgs a) {
 #pragma unroll
     for (int w = 0; w < FL_W; ++w) {
         const int q = q0 + 16 * w + fr;
+        // exact delta of this query = sum over ALL keys of P o dP (the four lane groups hold disjoint keys), and the correction
+        //   dQ = sum_j P (dP - delta) K = [sum_j P (dP - estimate) K] - (delta - estimate) [sum_j P K]
+        const float dexact = group_sum4(dex[w]);
+        const float corr = dexact - dl[w];
         if (q < nq) {
+            if (g == 0) a.delta[(b * a.heads + h) * a.nq + q] = dexact;
 #pragma unroll
             for (int dt = 0; dt < C::DT; ++dt) {
-                const bf16x4 ov = {(bf16)(dq[w][dt][0] * a.scale), (bf16)(dq[w][dt][1] * a.scale), (bf16)(dq[w][dt][2] * a.scale), (bf16)(dq[w][dt][3] * a.scale)};
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (dq[w][dt][e] - corr * bq[w][dt][e]) * a.scale;
+                const bf16x4 ov = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
                 *(bf16x4*)((bf16*)a.dq + b * a.dq_bs + (int64_t)q * a.dq_ts + hoff + dt * 16 + 4 * g) = ov;
             }
         }
