@@ -508,6 +508,46 @@ def run_train(ctx, workload, *, steps, warmup, batch=None, cfg_path=None, want_r
                  warmup=warmup, batch=B, hipgraph=use_graph and workload == 'A-train', extra=extra, roof=roof)
 
 
+def run_train_hostfed(ctx, *, steps, warmup, batch=None):
+    """The A-train step FED FROM THE HOST (misc/engine.py:202-204 copies every batch at the top of
+    the iteration): each step's batch starts as uint8 pixels in pageable host memory (what a DataLoader hands over), goes
+    through ``engine.DevicePrefetcher`` (pinned staging, side-stream copy two batches ahead) and enters the patch-embedding
+    kernel as uint8 (ToTensor + Normalize folded in).  Same model, optimizer and hipGraph step as the headline; the timed region
+    includes the H2D copies."""
+    torch, V, engine, args, world, rank, dev = ctx.torch, ctx.V, ctx.engine, ctx.args, ctx.world, ctx.rank, ctx.dev
+    cfg, model = ctx.build(CFG_A)
+    S, C = cfg.DATA.IMG_SIZE, cfg.MODEL.NUM_CLASSES
+    B = batch or 1024
+    opt = V.optim.FlatAdamW(engine.param_groups_no_decay_1d(model), model=model, lr=1e-4 * B * world / 256.0, weight_decay=0.05)
+    step = engine.TrainStep(model, opt, clip_grad=5.0, amp=not args.fp32, use_graph=not args.no_graph)
+    g = torch.Generator().manual_seed(cfg.SEED + rank)
+    host = [(torch.randint(0, 256, (B, 2, 3, S, S), generator=g, dtype=torch.uint8), (torch.rand(B, C, generator=g) > 0.75).float())
+            for _ in range(4)]                                   # four distinct pageable batches, cycled
+    total = warmup + steps + 3
+
+    def loader():
+        for i in range(total):
+            yield host[i % len(host)]
+
+    it = iter(engine.DevicePrefetcher(loader(), dev, depth=2))
+    for _ in range(3 + warmup):                                  # eager steps + capture, then W warm-up steps
+        x, y = next(it)
+        step.step(x, y)
+    ctx.fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        x, y = next(it)
+        loss = step.step(x, y)
+    ctx.fence()
+    elapsed = ctx.max_over_ranks(time.perf_counter() - t0)
+    if not math.isfinite(float(loss)):
+        raise SystemExit('bench.py: the host-fed steps diverged')
+    return {'metric': 'patch-pairs/sec fwd+bwd, host-fed uint8 batches', 'value': round(B * world * steps / elapsed, 1), 'unit': 'pairs/s',
+            'ms_per_step': round(1e3 * elapsed / steps, 3), 'steps': steps, 'h2d_bytes_per_step': B * 2 * 3 * S * S + B * C * 4,
+            'workload': f'{os.path.basename(CFG_A)} batch {B}/GPU: uint8 pixels from pageable host memory -> DevicePrefetcher (pinned, '
+                        f'side stream, depth 2) -> vited_patchify_u8; full train step, H2D inside the timed region'}
+
+
 def run_infer(ctx, *, steps, warmup, batch=None, cfg_path=None, want_roofline=True):
     """H-infer: pairwise similarity-matrix inference (hisfrag.py:161-302): every rank encodes its row block and streams all later
     images; one "step" = one whole similarity matrix."""
@@ -583,6 +623,9 @@ def main():
         gc.collect()
         torch.cuda.empty_cache()
         legs = {}
+        legs['A-train-hostfed'] = run_train_hostfed(ctx, steps=10, warmup=2)
+        gc.collect()
+        torch.cuda.empty_cache()
         legs['H-train'] = _brief(run_train(ctx, 'H-train', steps=5, warmup=2, want_roofline=want_roof))
         gc.collect()
         torch.cuda.empty_cache()

@@ -221,6 +221,23 @@ int vited_block_fwd(const float* x, float* y, int64_t batch, int64_t tokens, int
                     const float* bproj, const float* ln2_g, const float* ln2_b, const void* w1, const float* b1,
                     const void* w2, const float* b2, float eps, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* One decoder CrossBlock forward (CrossBlock.forward, vision_transformer.py:268-272: self-attention branch, cross-attention of the
+ * image-2 tokens over the image-1 features, MLP branch) behind one call - a launch sequence on `stream`, inference form.
+ *   x          fp32 [batch * tokens, dim]       the image-2 token stream (cls + patches)
+ *   context    fp32 [batch * ctx_tokens, dim]   the encoder features of image 1
+ *   y          fp32 [batch * tokens, dim]; may not alias x
+ *   ln1 / lnq / lnc / ln2   norm1, norm_cross, norm_context, norm2 (gamma, beta fp32)
+ *   wqkv [3 dim, dim], wproj, wq, wcproj [dim, dim], wkv [2 dim, dim], w1 [hidden, dim], w2 [dim, hidden]   bf16 dense; biases fp32
+ *   workspace  >= vited_cross_block_workspace_bytes(), 256-byte aligned */
+int64_t vited_cross_block_workspace_bytes(int64_t batch, int64_t tokens, int64_t ctx_tokens, int64_t dim, int64_t hidden, int heads);
+int vited_cross_block_fwd(const float* x, const float* context, float* y, int64_t batch, int64_t tokens, int64_t ctx_tokens,
+                          int64_t dim, int heads, int64_t hidden, const float* ln1_g, const float* ln1_b, const void* wqkv,
+                          const float* bqkv, const void* wproj, const float* bproj, const float* lnq_g, const float* lnq_b,
+                          const float* lnc_g, const float* lnc_b, const void* wq, const float* bq, const void* wkv,
+                          const float* bkv, const void* wcproj, const float* bcproj, const float* ln2_g, const float* ln2_b,
+                          const void* w1, const float* b1, const void* w2, const float* b2, float eps, void* workspace,
+                          int64_t workspace_bytes, void* stream);
+
 /* ---- optimizer step on the flat gradient buffer ----------------- */
 
 /* Gradient clip + AdamW + bf16 weight-shadow refresh + gradient zeroing in two launches; replaces

@@ -625,3 +625,74 @@ def test_pair_cached_decoder_at_config_h_tokens_pair_batch_512(vited, gpu, dtype
     tol = dict(rtol=2e-3, atol=2e-3) if dtype == torch.float32 else dict(rtol=3e-2, atol=3e-2)   # fp16 storage: 1e-3 relative
     torch.testing.assert_close(sim[i[pick], j[pick]].float().cpu(), ref, **tol)
     assert torch.equal(sim, sim.t()) and bool(torch.isfinite(sim.float()).all())
+
+
+def test_streamed_similarity_is_block_resident_resumable_and_matches_the_oracle(vited, gpu, tmp_path):
+    """``engine.pairwise_similarity`` with the HIP model streams (hisfrag.py:181-231): images come from the HOST as uint8 blocks
+    (a callable source, like the reference's per-row-block DataLoader), only ``block`` row images and ``col_block`` column
+    images are resident, finished row blocks are saved and skipped on a restart (hisfrag.py:181-195,243-246).
+      * parity: every pair against the CPU oracle's naive one-shot forward on (u8 / 255 - 0.5) / 0.5;
+      * resume: a run killed after three row blocks and restarted equals the uninterrupted run bit for bit, and the restart
+        does not touch the finished rows again;
+      * residency: the peak of allocated device memory does not grow with the number of images (24 vs 96)."""
+    s = vo.ViTEDShape(img_size=128, patch_size=16, num_classes=1, num_heads=6, depth=1, c_depth=2)
+    torch.manual_seed(23)
+    oracle = vo.OracleViTED(s).eval()
+    model = _hip_model(vited, s, gpu, torch.bfloat16).eval()
+    model.load_state_dict(oracle.state_dict())
+    g = torch.Generator().manual_seed(9)
+    n = 37
+    u8 = torch.randint(0, 256, (96, 3, 128, 128), generator=g, dtype=torch.uint8)
+    touched = []
+
+    def source(lo, hi):                       # host-side loader: returns uint8 CPU blocks
+        touched.append((lo, hi))
+        return u8[lo:hi]
+
+    kw = dict(block=5, col_block=7, pair_batch=16, amp=True)
+    sim = vited.engine.pairwise_similarity(model, source, n_images=n, **kw)
+    assert sim.shape == (n, n) and sim.dtype == torch.float16 and torch.equal(sim, sim.t())
+    i, j = torch.triu_indices(n, n)
+    f = (u8[:n].float() / 255.0 - 0.5) / 0.5
+    with torch.no_grad():
+        ref = torch.cat([oracle(torch.stack([f[i[k:k + 64]], f[j[k:k + 64]]], dim=1)).reshape(-1) for k in range(0, i.numel(), 64)])
+    torch.testing.assert_close(sim[i, j].float().cpu(), ref, rtol=3e-2, atol=3e-2)
+    # a host tensor works like the callable
+    assert torch.equal(vited.engine.pairwise_similarity(model, u8[:n], **kw), sim)
+
+    # kill after the third row block, restart from the saved state
+    state = str(tmp_path / 'similarity_rank0.pt')
+
+    class Killed(Exception):
+        pass
+
+    def kill_after_three(a0, a1):
+        if a1 >= 15:
+            raise Killed
+
+    with pytest.raises(Killed):
+        vited.engine.pairwise_similarity(model, source, n_images=n, state_path=state, after_row_block=kill_after_three, **kw)
+    saved = torch.load(state, weights_only=True)
+    assert saved['done_rows'] == 15 and not saved['is_finished']
+    touched.clear()
+    resumed = vited.engine.pairwise_similarity(model, source, n_images=n, state_path=state, **kw)
+    assert torch.equal(resumed, sim), 'a resumed run must equal the uninterrupted one'
+    assert min(lo for lo, _ in touched) >= 15, f'finished rows were read again: {touched[:4]}'
+    assert torch.load(state, weights_only=True)['is_finished']
+    # a state file of another run (different image count) is ignored, not trusted
+    again = vited.engine.pairwise_similarity(model, source, n_images=n - 1, state_path=state, **kw)
+    assert torch.equal(again, sim[:n - 1, :n - 1])
+
+    # residency: O(block + col_block), not O(n)
+    def peak(count):
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        vited.engine.pairwise_similarity(model, source, n_images=count, **kw)
+        torch.cuda.synchronize()
+        return torch.cuda.max_memory_allocated() - base
+
+    p24, p96 = peak(24), peak(96)
+    per_image_cache = 65 * 384 * (4 + 2)           # image-2 tokens fp32 + cached queries bf16, what an all-image cache would hold
+    assert p96 - p24 < 8 * per_image_cache + 96 * 96 * 2 + 4 * 96 * 97 // 2 + (1 << 20), (p24, p96)
+    assert 72 * per_image_cache > 8 * per_image_cache + (2 << 20)    # i.e. the bound is far below what 72 more resident images cost

@@ -525,3 +525,34 @@ def test_block_fwd_matches_the_oracle_block(vited, gpu, batch, tokens, heads):
                             bf(blk.attn.proj.weight), g(blk.attn.proj.bias), g(blk.norm2.weight), g(blk.norm2.bias), bf(blk.mlp.fc1.weight),
                             g(blk.mlp.fc1.bias), bf(blk.mlp.fc2.weight), g(blk.mlp.fc2.bias))
     torch.testing.assert_close(y.cpu(), want, rtol=3e-2, atol=3e-2)
+
+
+@pytest.mark.parametrize('batch,tokens,ctx_tokens,heads', [(64, 65, 64, 12), (5, 65, 64, 12), (2, 257, 256, 6)])
+def test_cross_block_fwd_matches_the_oracle_block(vited, gpu, batch, tokens, ctx_tokens, heads):
+    """vited_cross_block_fwd (CrossBlock.forward, vision_transformer.py:268-272, as one C-ABI call) against the CPU oracle's
+    ``decoder_block`` on the same fp32 parameters: bf16 tolerance (3e-2).  65 / 64 tokens at 12 x 32 heads (config A; batch 64 =
+    4,160 rows takes the row-complete proj + norm_cross kernel and the fused MLP) and 257 / 256 tokens at 6 x 64 (config H's
+    head shape: the flash attention kernels)."""
+    from oracle import vited_oracle as vo
+    torch.manual_seed(batch + tokens)
+    s = vo.ViTEDShape(num_heads=heads)
+    blk = vo._decoder_bag(s)
+    for p in blk.parameters():
+        if p.dim() > 1:
+            torch.nn.init.trunc_normal_(p, std=.04)
+        else:
+            torch.nn.init.normal_(p, std=.05)
+    for nm in (blk.norm1, blk.norm_cross, blk.norm_context, blk.norm2):
+        nm.weight.data.add_(1.0)
+    x, ctx = torch.randn(batch, tokens, 384), torch.randn(batch, ctx_tokens, 384)
+    with torch.no_grad():
+        want = vo.decoder_block(blk, x, ctx, heads)
+    g = lambda t: t.detach().to(gpu)
+    bf = lambda t: t.detach().to(gpu).to(torch.bfloat16).contiguous()
+    ln = lambda m: (g(m.weight), g(m.bias))
+    ca = blk.cross_attn
+    y = vited.ops.cross_block_fwd(g(x), g(ctx), heads, ln(blk.norm1), bf(blk.attn.qkv.weight), g(blk.attn.qkv.bias), bf(blk.attn.proj.weight),
+                                  g(blk.attn.proj.bias), ln(blk.norm_cross), ln(blk.norm_context), bf(ca.q.weight), g(ca.q.bias),
+                                  bf(ca.kv.weight), g(ca.kv.bias), bf(ca.proj.weight), g(ca.proj.bias), ln(blk.norm2),
+                                  bf(blk.mlp.fc1.weight), g(blk.mlp.fc1.bias), bf(blk.mlp.fc2.weight), g(blk.mlp.fc2.bias))
+    torch.testing.assert_close(y.cpu(), want, rtol=3e-2, atol=3e-2)

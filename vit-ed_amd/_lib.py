@@ -54,6 +54,8 @@ SIGNATURES = {
     'vited_mlp_fwd': (_i, [_p, _i64, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _p, _p, _p, _p, _i64, _i64, _i64, _f, _p]),
     'vited_block_workspace_bytes': (_i64, [_i64, _i64, _i64, _i64, _i]),
     'vited_block_fwd': (_i, [_p, _p, _i64, _i64, _i64, _i, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _i64, _p]),
+    'vited_cross_block_workspace_bytes': (_i64, [_i64, _i64, _i64, _i64, _i64, _i]),
+    'vited_cross_block_fwd': (_i, [_p, _p, _p, _i64, _i64, _i64, _i64, _i, _i64] + [_p] * 22 + [_f, _p, _i64, _p]),
     'vited_adamw_workspace_bytes': (_i64, []),
     'vited_adamw_step': (_i, [_p, _i, _i64, _p, _i64, _p, _f, _i, _p, _p, _i64, _p]),
     'vited_attention_fwd': (_i, [_p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _p, _i, _i64, _i,

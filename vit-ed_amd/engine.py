@@ -68,18 +68,25 @@ class FlatGradients:
         rest = [p for p in params if id(p) not in early_ids]
         self.params = first + rest
         dev = self.params[0].device
-        total = sum(p.numel() for p in self.params)
+        # every view starts on a 64-byte boundary (config H's [1] head bias would otherwise leave everything behind it on an odd
+        # word: the kernels that add into these views use 16-byte accesses); the padding words stay zero
+        align = lambda n: (n + 15) // 16 * 16
+        self.offsets, off = [], 0
+        for i, p in enumerate(self.params):
+            self.offsets.append(off)
+            off += align(p.numel())
+            if i + 1 == len(first):
+                self.split = off                        # [0, split) = early bucket, [split, total) = the rest
+        total = off
+        if not first:
+            self.split = 0
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
         self.wire = torch.empty(total, dtype=torch.bfloat16, device=dev) if compress_bf16 else None
-        off = 0
-        self.views, self.offsets = [], []
-        for p in self.params:
-            v = self.flat[off: off + p.numel()].view_as(p)
+        self.views = []
+        for p, o in zip(self.params, self.offsets):
+            v = self.flat[o: o + p.numel()].view_as(p)
             p.grad = v
             self.views.append(v)
-            self.offsets.append(off)
-            off += p.numel()
-        self.split = sum(p.numel() for p in first)     # [0, split) = early bucket, [split, total) = the rest
         self._pending = []
 
     def buckets(self):
@@ -617,52 +624,153 @@ def shard_rows_by_pair_count(n: int, world: int):
     return bounds
 
 
+def _row_block_pairs(a0, a1, c0, c1, dev):
+    """Pairs (i, j), i in [a0, a1), j in [c0, c1), j >= i, row-major - the order every rank and the assembler agree on."""
+    ii = torch.arange(a0, a1, device=dev).view(-1, 1).expand(a1 - a0, c1 - c0)
+    jj = torch.arange(c0, c1, device=dev).view(1, -1).expand(a1 - a0, c1 - c0)
+    keep = jj >= ii
+    return ii[keep], jj[keep]
+
+
+class _ImageSource:
+    """Images by index range for the streamed similarity run: a tensor [n, C, S, S] (host or device, uint8 or float) or a
+    callable ``(lo, hi) -> tensor`` with ``n_images`` (the reference re-opens its dataset with ``lower_bound`` per row block,
+    hisfrag.py:201-211).  Host blocks travel through ``DevicePrefetcher`` (pinned staging, side stream, uint8 stays uint8)."""
+
+    def __init__(self, images, n_images, dev):
+        self.images, self.dev = images, dev
+        if torch.is_tensor(images):
+            self.n = images.shape[0]
+        else:
+            if n_images is None:
+                raise ValueError('pairwise_similarity: a callable image source needs n_images')
+            self.n = int(n_images)
+
+    def host_block(self, lo, hi):
+        return self.images[lo:hi] if torch.is_tensor(self.images) else self.images(lo, hi)
+
+    def block(self, lo, hi):
+        t = self.host_block(lo, hi)
+        return t if t.device == self.dev else t.to(self.dev, non_blocking=True)
+
+    def column_blocks(self, start, step):
+        """(c0, c1, images on the device) for c0 = start, start + step, ...; host blocks are copied one block ahead."""
+        spans = [(c0, min(c0 + step, self.n)) for c0 in range(start, self.n, step)]
+        if not spans:
+            return
+        probe = self.host_block(*spans[0])
+        if probe.device == self.dev or self.dev.type != 'cuda':
+            for i, (c0, c1) in enumerate(spans):
+                yield c0, c1, (probe if i == 0 else self.host_block(c0, c1)).to(self.dev)
+            return
+        loader = ((probe if i == 0 else self.host_block(c0, c1), torch.tensor([c0, c1])) for i, (c0, c1) in enumerate(spans))
+        for (imgs, _), (c0, c1) in zip(DevicePrefetcher(loader, self.dev, depth=1), spans):
+            yield c0, c1, imgs
+
+
+def _similarity_scores_streamed(model, src, r0, r1, *, block, col_block, pair_batch, amp, state_path, meta, after_row_block):
+    """This rank's score vector (pairs of rows [r0, r1) in _row_block_pairs order, row block by row block, column block by
+    column block) with O(block + col_block) images resident: per row block the encoder output and the cross-attention K / V of
+    ``block`` images; per column block the image-2 token cache of ``col_block`` images.  Finished row blocks are saved to
+    ``state_path`` (what hisfrag.py:181-195,243-246 does with ``*_result_rank{r}.pt``) and skipped on a restart."""
+    n, dev = src.n, src.dev
+    total = sum(n - i for i in range(r0, r1))
+    scores = torch.empty(total, dtype=torch.float32, device=dev)
+    done_rows, off = r0, 0
+    if state_path is not None and os.path.exists(state_path):
+        st = torch.load(state_path, map_location='cpu', weights_only=True)
+        if st.get('meta') == meta and r0 <= int(st['done_rows']) <= r1:
+            done_rows = int(st['done_rows'])
+            off = int(st['scores'].numel())
+            scores[:off] = st['scores'].to(dev)
+    dtype_ctx = lambda: torch.autocast(dev.type, dtype=torch.bfloat16, enabled=amp)
+    for a0 in range(r0, r1, block):
+        a1 = min(a0 + block, r1)
+        if a1 <= done_rows:
+            continue                                                        # finished before the restart
+        with dtype_ctx():
+            feats = model(src.block(a0, a1), forward_first_part=True)       # encoder once per row block
+            kvs = model.cache_context_kv(feats)                             # K / V of every decoder block, once per row block
+        del feats
+        for c0, c1, imgs2 in src.column_blocks(a0, col_block):
+            with dtype_ctx():
+                tokens2, q0 = model.cache_image2_tokens(imgs2)              # everything that depends on image 2 alone
+            ii, jj = _row_block_pairs(a0, a1, c0, c1, dev)
+            for p0 in range(0, ii.numel(), pair_batch):
+                with dtype_ctx():
+                    out = model.forward_pairs_cached(tokens2, jj[p0:p0 + pair_batch] - c0, kvs, ii[p0:p0 + pair_batch] - a0, q0)
+                cnt = out.numel()
+                scores[off: off + cnt] = out.float().reshape(-1)
+                off += cnt
+            del tokens2, q0, imgs2
+        del kvs
+        if state_path is not None:
+            tmp = state_path + '.tmp'
+            torch.save({'meta': meta, 'done_rows': a1, 'scores': scores[:off].cpu(), 'is_finished': a1 == r1}, tmp)
+            os.replace(tmp, state_path)                                     # a kill between blocks never leaves a torn file
+        if after_row_block is not None:
+            after_row_block(a0, a1)
+    assert off == total, (off, total)
+    return scores
+
+
 @torch.no_grad()
 def pairwise_similarity(model, images, *, rank: int = 0, world: int = 1, block: int = 64, pair_batch: int = 512,
-                        amp: bool = True, group=None, pair_cache: bool = True):
+                        amp: bool = True, group=None, pair_cache: bool = True, col_block: int = 256, n_images=None,
+                        state_path=None, after_row_block=None):
     """similarity[i, j] = similarity[j, i] = fp16(logit(model(features(image_i), image_j))) for i <= j.
 
     What hisfrag.py:161-302 computes, re-plumbed: the encoder runs ONCE per image of this rank's row
-    block, the decoder runs on `pair_batch` pairs at a time, image-2 gathers happen inside the
-    patch-embed kernel (index array, no materialised [P,3,S,S] copy - SURVEY section 7 last bullet), and
-    the ranks exchange their score vectors with ONE all-gather (RCCL on GPU) instead of the reference's
-    per-rank files + 120 s polling.  Every rank returns the full symmetric [n, n] fp16 matrix of raw
-    logits (callers take 1 - similarity as the distance, hisfrag.py:294-296)."""
-    n = images.shape[0]
-    dev = images.device
-    bounds = shard_rows_by_pair_count(n, world)
-    r0, r1 = bounds[rank], bounds[rank + 1]
-    dtype_ctx = torch.autocast(dev.type, dtype=torch.bfloat16, enabled=amp)
-    by_index = bool(getattr(model, 'supports_x2_index', False))
-    # pair cache (HIP model): image-2 tokens once per image, cross-attention K / V once per row block, both read by index
-    cached = bool(getattr(model, 'supports_pair_cache', False)) and pair_cache and r1 > r0
-    scores = []
+    block, the decoder runs on `pair_batch` pairs at a time, and the ranks exchange their score vectors with ONE
+    all-gather (RCCL on GPU) instead of the reference's per-rank files + 120 s polling.  Every rank returns the full
+    symmetric [n, n] fp16 matrix of raw logits (callers take 1 - similarity as the distance, hisfrag.py:294-296).
+
+    With the HIP model (``supports_pair_cache``) the run STREAMS: ``images`` may be a host tensor (uint8 or float) or a
+    callable ``(lo, hi) -> tensor`` (+ ``n_images``), only ``block`` row images and ``col_block`` column images are
+    resident at a time, scores land in one pre-sized buffer, and with ``state_path`` finished row blocks are saved and a
+    restarted run skips them (hisfrag.py:181-195,243-246).  Models without the cache (the CPU oracle in the tests) take the
+    plain path on a resident image tensor."""
+    cached = bool(getattr(model, 'supports_pair_cache', False)) and pair_cache
     was_training = model.training
     model.eval()
-    tokens2 = q0 = None
     if cached:
-        with dtype_ctx:
-            lo = r0                                                        # this rank only ever needs images j >= its first row
-            parts = [model.cache_image2_tokens(images[c:min(c + 256, n)]) for c in range(lo, n, 256)]
-            tokens2 = torch.cat([t for t, _ in parts])
-            q0 = torch.cat([q for _, q in parts]) if parts[0][1] is not None else None
-    for a0 in range(r0, r1, block):
-        a1 = min(a0 + block, r1)
-        with dtype_ctx:
-            feats = model(images[a0:a1], forward_first_part=True)          # encoder once per row block
-            kvs = model.cache_context_kv(feats) if cached else None
-        ii, jj = torch.triu_indices(a1 - a0, n - a0, offset=0, device=dev)  # pairs (a0+ii, a0+jj), jj >= ii
-        for c0 in range(0, ii.numel(), pair_batch):
-            i_sub, j_sub = ii[c0:c0 + pair_batch], (jj[c0:c0 + pair_batch] + a0)
+        dev = next(model.parameters()).device
+        src = _ImageSource(images, n_images, dev)
+        n = src.n
+        bounds = shard_rows_by_pair_count(n, world)
+        r0, r1 = bounds[rank], bounds[rank + 1]
+        meta = {'n': n, 'r0': r0, 'r1': r1, 'block': block, 'col_block': col_block}
+        mine = _similarity_scores_streamed(model, src, r0, r1, block=block, col_block=col_block, pair_batch=pair_batch, amp=amp,
+                                           state_path=state_path, meta=meta, after_row_block=after_row_block)
+        enumerate_pairs = lambda lo, hi: [(_row_block_pairs(a0, min(a0 + block, hi), c0, min(c0 + col_block, n), dev))
+                                          for a0 in range(lo, hi, block) for c0 in range(a0, n, col_block)]
+    else:
+        n = images.shape[0]
+        dev = images.device
+        bounds = shard_rows_by_pair_count(n, world)
+        r0, r1 = bounds[rank], bounds[rank + 1]
+        dtype_ctx = torch.autocast(dev.type, dtype=torch.bfloat16, enabled=amp)
+        by_index = bool(getattr(model, 'supports_x2_index', False))
+        scores = []
+        for a0 in range(r0, r1, block):
+            a1 = min(a0 + block, r1)
             with dtype_ctx:
-                if cached:
-                    out = model.forward_pairs_cached(tokens2, j_sub - r0, kvs, i_sub, q0)
-                elif by_index:
-                    out = model(feats[i_sub], images, x2_index=j_sub)
-                else:
-                    out = model(feats[i_sub], images[j_sub])
-            scores.append(out.float().reshape(-1))
-    mine = torch.cat(scores) if scores else torch.zeros(0, device=dev)
+                feats = model(images[a0:a1], forward_first_part=True)          # encoder once per row block
+            ii, jj = torch.triu_indices(a1 - a0, n - a0, offset=0, device=dev)  # pairs (a0+ii, a0+jj), jj >= ii
+            for c0 in range(0, ii.numel(), pair_batch):
+                i_sub, j_sub = ii[c0:c0 + pair_batch], (jj[c0:c0 + pair_batch] + a0)
+                with dtype_ctx:
+                    out = model(feats[i_sub], images, x2_index=j_sub) if by_index else model(feats[i_sub], images[j_sub])
+                scores.append(out.float().reshape(-1))
+        mine = torch.cat(scores) if scores else torch.zeros(0, device=dev)
+
+        def enumerate_pairs(lo, hi):
+            out = []
+            for a0 in range(lo, hi, block):
+                a1 = min(a0 + block, hi)
+                ii, jj = torch.triu_indices(a1 - a0, n - a0, offset=0, device=dev)
+                out.append((ii + a0, jj + a0))
+            return out
     model.train(was_training)
 
     # exchange: pad to the largest shard, one all-gather, then every rank rebuilds the matrix
@@ -676,16 +784,11 @@ def pairwise_similarity(model, images, *, rank: int = 0, world: int = 1, block: 
         gathered = [mine]
     sim = torch.zeros((n, n), dtype=torch.float16, device=dev)
     for r in range(world):
-        rows = torch.arange(bounds[r], bounds[r + 1], device=dev)
-        if rows.numel() == 0:
-            continue
-        # same enumeration order as the compute loop: row blocks of `block`, triu inside each block
         off = 0
-        for a0 in range(bounds[r], bounds[r + 1], block):
-            a1 = min(a0 + block, bounds[r + 1])
-            ii, jj = torch.triu_indices(a1 - a0, n - a0, offset=0, device=dev)
+        for ii, jj in enumerate_pairs(bounds[r], bounds[r + 1]):      # the same enumeration order as the compute loop
             vals = gathered[r][off: off + ii.numel()].to(torch.float16)
-            sim[ii + a0, jj + a0] = vals
-            sim[jj + a0, ii + a0] = vals
+            sim[ii, jj] = vals
+            sim[jj, ii] = vals
             off += ii.numel()
+        assert off == counts[r], (r, off, counts[r])
     return sim

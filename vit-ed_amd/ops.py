@@ -322,6 +322,8 @@ def linear_bwd_weight_batched(items, accumulate: bool) -> bool:
             return False
         assert dw.dtype == torch.float32 and dw.is_contiguous() and dw.numel() == dy.shape[1] * x.shape[1]
         assert db is None or (db.dtype == torch.float32 and db.is_contiguous() and db.numel() == dy.shape[1])
+        if dw.data_ptr() % 16 or (db is not None and db.data_ptr() % 16) or dy.data_ptr() % 16 or x.data_ptr() % 16:
+            return False                 # the batched kernels use 16-byte accesses throughout
     i64, vp = C.c_int64 * n, C.c_void_p * n
     M = i64(*[it[0].shape[0] for it in items])
     N = i64(*[it[0].shape[1] for it in items])
@@ -448,6 +450,29 @@ def block_fwd(x, heads: int, ln1_g, ln1_b, wqkv, bqkv, wproj, bproj, ln2_g, ln2_
     _lib.check(lib.vited_block_fwd(_ptr(x), _ptr(y), b, n, d, heads, hidden, _ptr(ln1_g), _ptr(ln1_b), _ptr(wqkv), _ptr(bqkv), _ptr(wproj),
                                    _ptr(bproj), _ptr(ln2_g), _ptr(ln2_b), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), float(eps), base,
                                    ws.numel() * 4 - (base - ws.data_ptr()), _stream()), 'vited_block_fwd')
+    return y
+
+
+def cross_block_fwd(x, context, heads: int, ln1, wqkv, bqkv, wproj, bproj, lnq, lnc, wq, bq, wkv, bkv, wcproj, bcproj, ln2, w1, b1, w2, b2,
+                    eps: float = 1e-6):
+    """Decoder CrossBlock forward through ``vited_cross_block_fwd``: x fp32 [B, N2, D], context fp32 [B, N1, D] -> y fp32 [B, N2, D]
+    (bf16 weights, inference form).  ln1 / lnq / lnc / ln2 = (gamma, beta) of norm1 / norm_cross / norm_context / norm2."""
+    _need_gpu(x, context, wqkv, wproj, wq, wkv, wcproj, w1, w2)
+    assert x.dtype == context.dtype == torch.float32 and x.dim() == context.dim() == 3 and x.is_contiguous() and context.is_contiguous()
+    assert all(t.dtype == torch.bfloat16 and t.is_contiguous() for t in (wqkv, wproj, wq, wkv, wcproj, w1, w2))
+    b, n, d = x.shape
+    nc = context.shape[1]
+    assert context.shape == (b, nc, d)
+    hidden = w1.shape[0]
+    lib = _lib.load()
+    y = torch.empty_like(x)
+    ws = workspace(lib.vited_cross_block_workspace_bytes(b, n, nc, d, hidden, heads) + 256, x.device)
+    base = (ws.data_ptr() + 255) // 256 * 256
+    _lib.check(lib.vited_cross_block_fwd(_ptr(x), _ptr(context), _ptr(y), b, n, nc, d, heads, hidden, _ptr(ln1[0]), _ptr(ln1[1]), _ptr(wqkv),
+                                         _ptr(bqkv), _ptr(wproj), _ptr(bproj), _ptr(lnq[0]), _ptr(lnq[1]), _ptr(lnc[0]), _ptr(lnc[1]),
+                                         _ptr(wq), _ptr(bq), _ptr(wkv), _ptr(bkv), _ptr(wcproj), _ptr(bcproj), _ptr(ln2[0]), _ptr(ln2[1]),
+                                         _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), float(eps), base, ws.numel() * 4 - (base - ws.data_ptr()),
+                                         _stream()), 'vited_cross_block_fwd')
     return y
 
 
