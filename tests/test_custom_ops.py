@@ -31,6 +31,11 @@ def test_operators_are_registered_with_fake_kernels(vited):
     outs = torch.ops.vited.mlp_backward(y, x, z, h, w1, w2)
     assert [tuple(t.shape) for t in outs] == [(3, 65, 384), (1536, 384), (1536,), (384, 1536), (384,)]
     assert torch.ops.vited.patchify(torch.empty(2, 3, 64, 64, device=m), 8, True).shape == (2, 64, 192)
+    wp = torch.empty(384, 384, device=m)
+    y, h, mean, rstd = torch.ops.vited.linear_residual_layernorm(x.bfloat16(), wp, g, x, g, g, 1e-6)
+    assert y.shape == h.shape == x.shape and y.dtype == torch.float32 and h.dtype == torch.bfloat16 and mean.shape == (195,)
+    dx, dg, db = torch.ops.vited.linear_layernorm_backward(torch.empty(3, 65, 1152, device=m), w, x, g, mean, rstd, None)
+    assert dx.shape == x.shape and dg.shape == db.shape == (384,)
 
 
 def test_operators_have_no_cpu_kernel(vited):
@@ -106,6 +111,35 @@ def test_custom_ops_match_torch_reference(vited, gpu, lowp):
     o_ref, g_ref = _grads(sdpa_ref, [qkv])
     _close(o, o_ref, tol)
     _close(g[0], g_ref[0], 2 * tol)
+    # residual Linear + the LayerNorm behind it (one kernel), forward and autograd, against x + F.linear -> F.layer_norm
+    if lowp:
+        wp, bp = _rand((D, D), gpu, 20, 0.05), _rand((D,), gpu, 21, 0.1)
+        res = _rand((B, N, D), gpu, 22, 2.0)
+        wy, wh = _rand((B, N, D), gpu, 23), _rand((B, N, D), gpu, 24)
+
+        def fused(a, w, b, r, gm, bt):
+            y, h, _, _ = torch.ops.vited.linear_residual_layernorm(a.to(dt), w, b, r, gm, bt, 1e-6)
+            return y * wy + h.float() * wh
+
+        def plain(a, w, b, r, gm, bt):
+            y = r + F.linear(a, w, b)
+            return y * wy + F.layer_norm(y, (D,), gm, bt, 1e-6) * wh
+
+        o, g = _grads(fused, [x, wp, bp, res, gamma, beta])
+        o_ref, g_ref = _grads(plain, [x, wp, bp, res, gamma, beta])
+        _close(o, o_ref, tol)
+        for a, b in zip(g, g_ref):
+            _close(a, b, 2 * tol)
+        # ... and the backward-only pairing: dX GEMM + LayerNorm backward in one kernel
+        xin = _rand((B, N, D), gpu, 25, 1.5)
+        mu, var = xin.mean(-1), xin.var(-1, unbiased=False)
+        dyq = _rand((B, N, 3 * D), gpu, 26)
+        dx, dg_, db_ = torch.ops.vited.linear_layernorm_backward(dyq, w, xin, gamma, mu.reshape(-1), (var + 1e-6).rsqrt().reshape(-1), None)
+        xr, gr, br = xin.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+        F.linear(F.layer_norm(xr, (D,), gr, br, 1e-6), w).backward(dyq)
+        _close(dx, xr.grad, tol)
+        _close(dg_, gr.grad, tol)
+        _close(db_, br.grad, tol)
     # patchify + linear == Conv2d(k = s = p)
     img = _rand((B, 3, 64, 64), gpu, 11)
     cw, cb = _rand((D, 3, 8, 8), gpu, 12, 0.05), _rand((D,), gpu, 13, 0.1)

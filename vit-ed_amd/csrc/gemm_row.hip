@@ -100,6 +100,9 @@ gemm_row_kernel(const RowArgs a) {
     const int rsub = lane >> 2, cp = lane & 3;
     const int csrc = (cp ^ C::swz(rsub)) * 8;
     int64_t ar = m0 + wave * 16 + rsub;
+#ifdef ROW_DBG_A_RESIDENT                    // timing experiment: every workgroup stages the FIRST tile's rows (A served by L2, not HBM)
+    ar = wave * 16 + rsub;
+#endif
     ar = ar < a.M ? ar : a.M - 1;            // rows past M are staged from the last row and never stored
     const bf16* pa = a.A + ar * a.lda + csrc;
     const bf16* pa8 = pa;
@@ -182,6 +185,13 @@ gemm_row_kernel(const RowArgs a) {
     };
     if (MT == 9 && wave == 0) mainloop(std::integral_constant<int, 5>{});
     else mainloop(std::integral_constant<int, 4>{});
+#ifdef ROW_DBG_NO_EPI                        // timing experiment: main loop only
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) asm volatile("" ::"v"(acc[i][j]));
+    return;
+#endif
 
     // ---- epilogue: PASS_ROWS rows per pass through the fp32 scratch, then the LayerNorm row loop (half-wave per row)
     float* sc = (float*)smem;

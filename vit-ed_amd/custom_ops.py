@@ -13,6 +13,8 @@ These are the op-level building blocks of the reference's layers, usable from or
   ``vited::mlp``               timm ``Mlp`` fc1 -> GELU(erf) -> fc2 (:115,259)        vited_gemm (GELU / GELU' epilogues)
   ``vited::attention``         ``F.scaled_dot_product_attention`` (:60-65,181-186)    vited_attention_fwd / _bwd
   ``vited::patchify``          im2col of timm ``PatchEmbed``'s Conv2d(k=s=p) (:383)   vited_patchify
+  ``vited::linear_residual_layernorm``  ``x = x + proj(...)`` followed by the next      vited_linear_residual_layernorm_fwd,
+                               sub-block's ``norm(x)`` (:124-127, 268-272)             vited_linear_layernorm_bwd
   ===========================  =====================================================  ==============================
 
 The model itself (``model.VisionTransformerCustom``) drives the same C entry points through two coarser
@@ -217,6 +219,81 @@ register_autograd('vited::mlp', _mlp_backward, setup_context=_mlp_setup)
 
 
 # ---------------------------------------------------------------------------------------------
+# residual Linear fused with the LayerNorm that follows it on the residual stream (gemm_row.hip)
+# ---------------------------------------------------------------------------------------------
+@custom_op('vited::linear_residual_layernorm', mutates_args=(), device_types='cuda')
+def linear_residual_layernorm(a: Tensor, weight: Tensor, bias: Optional[Tensor], residual: Tensor, gamma: Tensor, beta: Tensor,
+                              eps: float) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+    """y = residual + a W^T + b (fp32) and h = LayerNorm(y; gamma, beta) (bf16) with its row statistics, in one kernel when the
+    row-complete tile covers the shape (384 output columns), as two kernels otherwise.  a [..., K], residual [..., N]."""
+    a2 = _act(a).to(_LOWP)
+    r2 = _rows(residual.float())
+    r2 = r2 if r2.stride(-1) == 1 else r2.contiguous()
+    w = _weight_for(a2, weight)
+    g, b = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+    if ops.linear_layernorm_supported(a2.shape[0], w.shape[0], a2.shape[1], a2.dtype):
+        y, h, mean, rstd = ops.linear_residual_layernorm_fwd(a2, w, _bias32(bias), r2, g, b, eps)
+    else:
+        from ._lib import EPI_RESIDUAL
+        y = ops.gemm(a2, w, b_layout=B_NK, epilogue=EPI_RESIDUAL, bias=_bias32(bias), residual=r2)
+        h, mean, rstd = ops.layernorm_fwd(y, g, b, eps, _LOWP)
+    return y.view(residual.shape), h.view(residual.shape), mean, rstd
+
+
+@linear_residual_layernorm.register_fake
+def _(a, weight, bias, residual, gamma, beta, eps):
+    rows = residual.numel() // residual.shape[-1]
+    return (residual.new_empty(residual.shape, dtype=torch.float32), residual.new_empty(residual.shape, dtype=_LOWP),
+            residual.new_empty(rows, dtype=torch.float32), residual.new_empty(rows, dtype=torch.float32))
+
+
+@custom_op('vited::linear_layernorm_backward', mutates_args=(), device_types='cuda')
+def linear_layernorm_backward(dy: Tensor, weight: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tensor,
+                              dx_in: Optional[Tensor]) -> Tuple[Tensor, Tensor, Tensor]:
+    """Input gradient of  y = LayerNorm(x; gamma, beta) W^T + b  given dy:  dx = (dx_in or 0) + LN'(dy W), dgamma, dbeta - the
+    input-gradient GEMM and the LayerNorm backward in one kernel (d LayerNorm-output never exists in memory)."""
+    dy2 = _act(dy).to(_LOWP)
+    x2 = _rows(x.float())
+    x2 = x2 if x2.stride(-1) == 1 else x2.contiguous()
+    wt = weight.detach().reshape(weight.shape[0], -1).t().to(_LOWP).contiguous()     # [K_in, N_out]: NT operand of dX = dY W
+    g = gamma.detach().float().contiguous()
+    din = None if dx_in is None else _rows(dx_in.float()).contiguous()
+    if ops.linear_layernorm_supported(dy2.shape[0], wt.shape[0], dy2.shape[1], dy2.dtype):
+        dx, _, dg, db = ops.linear_layernorm_bwd(dy2, wt, x2, g, mean, rstd, dx_in=din)
+    else:
+        dh = ops.gemm(dy2, wt, b_layout=B_NK, epilogue=EPI_STORE)
+        dx, _, dg, db = ops.layernorm_bwd(dh, x2, g, mean, rstd, dx_in=din)
+    return dx.view(x.shape), dg, db
+
+
+@linear_layernorm_backward.register_fake
+def _(dy, weight, x, gamma, mean, rstd, dx_in):
+    return (x.new_empty(x.shape, dtype=torch.float32), gamma.new_empty(gamma.shape, dtype=torch.float32),
+            gamma.new_empty(gamma.shape, dtype=torch.float32))
+
+
+def _lrl_setup(ctx, inputs, output):
+    a, weight, bias, residual, gamma, beta, _eps = inputs
+    y, _h, mean, rstd = output
+    ctx.save_for_backward(a, weight, y, gamma, mean, rstd)
+    ctx.has_bias = bias is not None
+    ctx.dtypes = (a.dtype, None if bias is None else bias.dtype, residual.dtype, beta.dtype)
+
+
+def _lrl_backward(ctx, dy, dh, _dmean, _drstd):
+    a, weight, y, gamma, mean, rstd = ctx.saved_tensors
+    # d(y) = dy + LN'(dh); then the residual passes it through and the Linear splits it into da, dW, db
+    dln, dgamma, dbeta = torch.ops.vited.layernorm_backward(dh, y, gamma, mean, rstd)
+    dtot = dln if dy is None else dln + dy.float()
+    da, dw, db = torch.ops.vited.linear_backward(dtot, a, weight, ctx.has_bias)
+    return (da.to(ctx.dtypes[0]), dw.to(weight.dtype), db.to(ctx.dtypes[1]) if ctx.has_bias else None, dtot.to(ctx.dtypes[2]),
+            dgamma.to(gamma.dtype), dbeta.to(ctx.dtypes[3]), None)
+
+
+register_autograd('vited::linear_residual_layernorm', _lrl_backward, setup_context=_lrl_setup)
+
+
+# ---------------------------------------------------------------------------------------------
 # scaled-dot-product attention (no mask, no dropout: the only form the reference uses)
 # ---------------------------------------------------------------------------------------------
 def _tokens(t: Tensor) -> Tensor:
@@ -295,4 +372,4 @@ for _name in ('vited::linear', 'vited::mlp', 'vited::attention'):
     torch.library.register_autocast(_name, 'cuda', _LOWP)
 
 OPERATORS = ('layernorm', 'layernorm_backward', 'linear', 'linear_backward', 'mlp', 'mlp_backward', 'attention',
-             'attention_backward', 'patchify')
+             'attention_backward', 'patchify', 'linear_residual_layernorm', 'linear_layernorm_backward')
