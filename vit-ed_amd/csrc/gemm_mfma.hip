@@ -743,7 +743,7 @@ gemm_tn_wide_kernel(const TwBatch batch, float* __restrict__ out_base, float* __
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
             const int64_t k = kc0 + wc * 96 + j * 16 + fq * 4;
-            if (n < N) *(f32x4*)(o + n * K + k) = acc[i][j];
+            if (n < N) *(f32x4*)(o + n * K + k) = acc[i][j];   // plain: the slab sum reads it back at once (nt here: +0.08 ms)
         }
     }
     if constexpr (BIAS) {
