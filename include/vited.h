@@ -96,6 +96,14 @@ int vited_patchify(const float* img, int64_t img_bs, const int64_t* batch_index,
 int vited_patchify_u8(const uint8_t* img, int64_t img_bs, const int64_t* batch_index, void* out, int out_dtype,
                       int64_t batch, int chans, int img_size, int patch, const float* mean, const float* std, void* stream);
 
+/* Patch-pair assembly on the device (data/datasets/div2k_patch.py:108-121,155-162; transforms.py:14-18): per sample a uint8
+ * region [chans, 2 S, 3 S] (the 3-column x 2-row grid of S x S cells the reference cuts with transforms.crop(patch, 3, 2)),
+ * the two cells of its pair (cells int32 [batch, 2], 0..5 row-major) and the erosion size e = ceil(S (1 - erosion_ratio))
+ * (erode int32 [batch], e <= S).  out uint8 [batch, 2, chans, S, S] = Resize(S)(CenterCrop(e)(cell)) with Pillow's 8-bit
+ * bilinear resample, bit for bit; ToTensor + Normalize then happen inside vited_patchify_u8.  cells / erode are DEVICE arrays. */
+int vited_crop_pairs_u8(const uint8_t* src, int64_t src_bs, const int* cells, const int* erode, uint8_t* out, int64_t batch,
+                        int chans, int img_size, void* stream);
+
 /* out[b, r] = (out_dtype) in[b, row_offset + r] for r < rows: drops the cls row of a token-gradient
  * tensor before the patch-embed weight gradient. in is fp32 [batch, in_rows, dim]. */
 int vited_slice_rows_cast(const float* in, void* out, int out_dtype, int64_t batch, int64_t in_rows,
@@ -187,7 +195,12 @@ int vited_linear_residual_layernorm_fwd(const void* a, int64_t lda, const void* 
 
 /* dh = dy . wt^T  (wt = the transposed weight shadow, bf16 [N, K]: dX of y = LN(x) W^T), never written anywhere;
  * dx_out = (dx_in ? dx_in : 0) + LN'(dh; x, mean, rstd, gamma)  fp32 (dx_out may alias dx_in), optional bf16 copy dx_lp;
- * dgamma / dbeta: column sums of dh * xhat / dh, overwritten or (accumulate != 0) added.  workspace >= *_workspace_bytes. */
+ * dgamma / dbeta: column sums of dh * xhat / dh, overwritten or (accumulate != 0) added.  workspace >= *_workspace_bytes.
+ * With dgamma == dbeta == null the column partials stay in `workspace` as [vited_linear_layernorm_bwd_partial_rows(M)][2][N]
+ * fp32 for vited_layernorm_bwd_finish_batched, which sums the partials of several LayerNorms in one launch. */
+int64_t vited_linear_layernorm_bwd_partial_rows(int64_t M);
+int vited_layernorm_bwd_finish_batched(int count, const float* const* partial, const int* nparts, float* const* dgamma,
+                                       float* const* dbeta, const int* accumulate, int64_t dim, void* stream);
 int64_t vited_linear_layernorm_bwd_workspace_bytes(int64_t M, int64_t N);
 int vited_linear_layernorm_bwd(const void* dy, int64_t lddy, const void* wt, int64_t ldwt, const float* x, int64_t ldx,
                                const float* gamma, const float* mean, const float* rstd, const float* dx_in,

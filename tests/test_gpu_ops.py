@@ -293,6 +293,14 @@ def test_linear_layernorm_bwd(vited, gpu, M, K):
     buf = dx_in.clone()
     ops.linear_layernorm_bwd(dy, wt, x, gamma, mean, rstd, dx_in=buf, dx_out=buf)
     assert torch.equal(buf, dx)
+    # deferred column sums: two LayerNorms finished by ONE launch (overwrite and accumulate), same numbers as the immediate form
+    queue = []
+    d1, _, g1, b1 = ops.linear_layernorm_bwd(dy, wt, x, gamma, mean, rstd, dx_in=dx_in, defer=queue)
+    acc_g2, acc_b2 = torch.full((N,), 2.0, device=gpu), torch.full((N,), -1.0, device=gpu)
+    ops.linear_layernorm_bwd(dy, wt, x, gamma, mean, rstd, dgamma=acc_g2, dbeta=acc_b2, defer=queue)
+    assert len(queue) == 2 and torch.equal(d1, dx)
+    ops.layernorm_bwd_finish(queue)
+    assert not queue and torch.equal(g1, dg) and torch.equal(b1, db) and torch.equal(acc_g2, acc_g) and torch.equal(acc_b2, acc_b)
     # the two-kernel form, for scale: same result within the bf16 rounding of dh it adds
     dh_lp = ops.gemm(dy, wt)
     dx_u, _, dg_u, _ = ops.layernorm_bwd(dh_lp, x, gamma, mean, rstd, dx_in=dx_in)

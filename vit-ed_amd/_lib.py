@@ -31,6 +31,7 @@ SIGNATURES = {
     'vited_cast_weights': (_i, [_p, _i, _i64, _p]),
     'vited_patchify': (_i, [_p, _i64, _p, _p, _i, _i64, _i, _i, _i, _p]),
     'vited_patchify_u8': (_i, [_p, _i64, _p, _p, _i, _i64, _i, _i, _i, _p, _p, _p]),
+    'vited_crop_pairs_u8': (_i, [_p, _i64, _p, _p, _p, _i64, _i, _i, _p]),
     'vited_slice_rows_cast': (_i, [_p, _p, _i, _i64, _i64, _i64, _i64, _i64, _p]),
     'vited_write_cls_row': (_i, [_p, _p, _p, _i64, _i64, _i64, _p]),
     'vited_sum_rows_workspace_bytes': (_i64, [_i64, _i64]),
@@ -48,6 +49,8 @@ SIGNATURES = {
     'vited_linear_bwd_weight_batched': (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _i64, _p]),
     'vited_linear_layernorm_supported': (_i, [_i64, _i64, _i64]),
     'vited_linear_residual_layernorm_fwd': (_i, [_p, _i64, _p, _i64, _p, _p, _i64, _p, _i64, _p, _p, _f, _p, _i64, _p, _p, _i64, _i64, _i64, _p]),
+    'vited_linear_layernorm_bwd_partial_rows': (_i64, [_i64]),
+    'vited_layernorm_bwd_finish_batched': (_i, [_i, _p, _p, _p, _p, _p, _i64, _p]),
     'vited_linear_layernorm_bwd_workspace_bytes': (_i64, [_i64, _i64]),
     'vited_linear_layernorm_bwd': (_i, [_p, _i64, _p, _i64, _p, _i64, _p, _p, _p, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i, _i64, _i64, _i64,
                                         _p, _i64, _p]),

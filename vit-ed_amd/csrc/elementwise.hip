@@ -236,6 +236,82 @@ extern "C" int vited_patchify_u8(const uint8_t* img, int64_t img_bs, const int64
 }
 
 // ------------------------------------------------------------------------------------------------
+// patch-pair assembly on the device (data/datasets/div2k_patch.py:108-121,155-162)
+//   the host hands over ONE uint8 region [C, 2 S, 3 S] per sample (the RandomCrop / CenterCrop of the augmented image) and the
+//   two grid cells its pair consists of; here every cell is eroded (CenterCrop(e)) and resized back to S x S exactly as
+//   torchvision's Resize does it on a PIL image: Pillow's 8-bit bilinear resample = horizontal pass, then vertical pass, each
+//   with two taps, 22-bit fixed-point coefficients and a uint8 intermediate (libImaging/Resample.c).  Bit-exact with Pillow
+//   (oracle/pair_crops.py pins the restatement against Pillow itself).
+// ------------------------------------------------------------------------------------------------
+struct ResampleTaps {
+    int x0, n;      // first tap, number of taps (1 or 2)
+    int k0, k1;     // fixed-point weights (sum = 2^22 up to rounding)
+};
+
+__device__ __forceinline__ ResampleTaps resample_taps(int xx, int in_size, int out_size) {
+    constexpr int PRECISION_BITS = 32 - 8 - 2;
+    const double scale = (double)in_size / (double)out_size;    // <= 1 (erosion shrinks the cell): filter support 1
+    const double center = (xx + 0.5) * scale;
+    int xmin = (int)(center - 1.0 + 0.5);
+    xmin = xmin < 0 ? 0 : xmin;
+    int xmax = (int)(center + 1.0 + 0.5);
+    xmax = (xmax < in_size ? xmax : in_size) - xmin;
+    double w0 = 1.0 - fabs((double)xmin - center + 0.5), w1 = xmax > 1 ? 1.0 - fabs((double)xmin + 1.0 - center + 0.5) : 0.0;
+    w0 = w0 < 0.0 ? 0.0 : w0;
+    w1 = w1 < 0.0 ? 0.0 : w1;
+    const double ww = w0 + w1;
+    ResampleTaps t;
+    t.x0 = xmin;
+    t.n = xmax > 1 ? 2 : 1;
+    t.k0 = (int)(0.5 + (w0 / ww) * (double)(1 << PRECISION_BITS));
+    t.k1 = (int)(0.5 + (w1 / ww) * (double)(1 << PRECISION_BITS));
+    return t;
+}
+
+__device__ __forceinline__ int resample_px(int p0, int p1, const ResampleTaps& t) {
+    constexpr int PRECISION_BITS = 32 - 8 - 2;
+    int acc = (1 << (PRECISION_BITS - 1)) + p0 * t.k0 + (t.n > 1 ? p1 * t.k1 : 0);
+    acc >>= PRECISION_BITS;
+    return acc < 0 ? 0 : (acc > 255 ? 255 : acc);
+}
+
+__global__ void __launch_bounds__(256)
+crop_pairs_u8_kernel(const uint8_t* __restrict__ src, int64_t src_bs, const int* __restrict__ cells, const int* __restrict__ erode,
+                     uint8_t* __restrict__ out, int chans, int S) {
+    const int64_t b = blockIdx.z;
+    const int img = blockIdx.y / chans, c = blockIdx.y % chans;
+    int cell = cells[b * 2 + img], e = erode[b];
+    cell = cell < 0 ? 0 : (cell > 5 ? 5 : cell);             // device-side arguments: clamp instead of reading out of bounds
+    e = e < 1 ? 1 : (e > S ? S : e);
+    const int off = (int)rint((S - e) / 2.0);                 // torchvision center_crop: int(round(.)), round half to even
+    const int r0 = (cell / 3) * S + off, c0 = (cell % 3) * S + off;
+    const uint8_t* base = src + b * src_bs + ((int64_t)c * 2 * S + r0) * (3 * S) + c0;   // eroded cell, row stride 3 S
+    uint8_t* o = out + (((b * 2 + img) * chans + c) * (int64_t)S) * S;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < S * S; i += gridDim.x * blockDim.x) {
+        const int y = i / S, x = i - y * S;
+        const ResampleTaps tx = resample_taps(x, e, S), ty = resample_taps(y, e, S);
+        const uint8_t* ra = base + (int64_t)ty.x0 * (3 * S) + tx.x0;
+        const int h0 = resample_px(ra[0], tx.n > 1 ? ra[1] : 0, tx);           // horizontal pass on the two source rows
+        int h1 = 0;
+        if (ty.n > 1) {
+            const uint8_t* rb = ra + 3 * S;
+            h1 = resample_px(rb[0], tx.n > 1 ? rb[1] : 0, tx);
+        }
+        o[i] = (uint8_t)resample_px(h0, h1, ty);                                // vertical pass on the uint8 intermediate
+    }
+}
+
+extern "C" int vited_crop_pairs_u8(const uint8_t* src, int64_t src_bs, const int* cells, const int* erode, uint8_t* out, int64_t batch,
+                                   int chans, int img_size, void* stream) {
+    if (!src || !cells || !erode || !out || batch <= 0 || chans <= 0 || img_size <= 0 || batch > 65535) return VITED_ERR_BAD_ARG;
+    if (src_bs < (int64_t)chans * 6 * img_size * img_size) return VITED_ERR_BAD_ARG;
+    const int per = img_size * img_size;
+    dim3 grid((unsigned)((per + 1023) / 1024 < 8 ? (per + 1023) / 1024 : 8), (unsigned)(2 * chans), (unsigned)batch);
+    hipLaunchKernelGGL(crop_pairs_u8_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, src_bs, cells, erode, out, chans, img_size);
+    return vited_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------
 // slice rows + cast
 // ------------------------------------------------------------------------------------------------
 template <typename D>

@@ -409,6 +409,8 @@ extern "C" int vited_linear_residual_layernorm_fwd(const void* a, int64_t lda, c
 // layernorm.hip
 int ln_bwd_finish(const float* partial, int nparts, int dim, float* dgamma, float* dbeta, int accumulate, hipStream_t s);
 
+extern "C" int64_t vited_linear_layernorm_bwd_partial_rows(int64_t M) { return M >= 1 ? row_tiles(M) : 0; }
+
 extern "C" int64_t vited_linear_layernorm_bwd_workspace_bytes(int64_t M, int64_t N) {
     return N == ROW_N && M >= 1 ? row_tiles(M) * 2 * ROW_N * (int64_t)sizeof(float) : 0;
 }
@@ -418,7 +420,8 @@ extern "C" int vited_linear_layernorm_bwd(const void* dy, int64_t lddy, const vo
                                           int64_t dx_in_ld, float* dx_out, int64_t dx_out_ld, void* dx_lp, int64_t dx_lp_ld,
                                           float* dgamma, float* dbeta, int accumulate, int64_t M, int64_t N, int64_t K,
                                           float* workspace, int64_t workspace_bytes, void* stream) {
-    if (!dy || !wt || !x || !gamma || !mean || !rstd || !dx_out || !dgamma || !dbeta || M <= 0 || N <= 0 || K <= 0) return VITED_ERR_BAD_ARG;
+    if (!dy || !wt || !x || !gamma || !mean || !rstd || !dx_out || M <= 0 || N <= 0 || K <= 0) return VITED_ERR_BAD_ARG;
+    if ((dgamma == nullptr) != (dbeta == nullptr)) return VITED_ERR_BAD_ARG;
     if (lddy < K || ldwt < K || ldx < N || dx_out_ld < N || (dx_in && dx_in_ld < N) || (dx_lp && dx_lp_ld < N)) return VITED_ERR_BAD_ARG;
     if (!row_shape_ok(M, N, K)) return VITED_ERR_UNSUPPORTED;
     if ((lddy & 7) || (ldwt & 7) || (ldx & 3) || (dx_out_ld & 3) || (dx_in && (dx_in_ld & 3)) || (dx_lp && (dx_lp_ld & 3))) return VITED_ERR_UNSUPPORTED;
@@ -430,6 +433,6 @@ extern "C" int vited_linear_layernorm_bwd(const void* dy, int64_t lddy, const vo
     r.dx_in = dx_in; r.ldxi = dx_in_ld; r.dx = dx_out; r.lddx = dx_out_ld; r.dx_lp = (bf16*)dx_lp; r.ldlp = dx_lp_ld;
     r.partial = workspace;
     const int rc = row_launch<ROW_MODE_BWD>(r, (hipStream_t)stream);
-    if (rc != VITED_OK) return rc;
+    if (rc != VITED_OK || !dgamma) return rc;     // dgamma == null: the caller keeps the partials and finishes several LayerNorms at once
     return ln_bwd_finish(workspace, (int)row_tiles(M), ROW_N, dgamma, dbeta, accumulate, (hipStream_t)stream);
 }

@@ -253,6 +253,62 @@ int ln_bwd_finish(const float* partial, int nparts, int dim, float* dgamma, floa
     return vited_check_launch();
 }
 
+// Several LayerNorms' column partials finished by ONE launch (the row-complete Linear + LayerNorm backward kernels of one
+// Function's backward leave their [tiles][2][dim] partials in caller-owned buffers; functions.py flushes them together).
+#define LNF_MAX_BATCH 16
+struct LnFinishBatch {
+    const float* partial[LNF_MAX_BATCH];
+    float* dgamma[LNF_MAX_BATCH];
+    float* dbeta[LNF_MAX_BATCH];
+    int nparts[LNF_MAX_BATCH];
+    int accumulate[LNF_MAX_BATCH];
+};
+
+__global__ void __launch_bounds__(16 * LNF_GROUPS)
+ln_bwd_finish_batch_kernel(const LnFinishBatch b, int dim) {
+    __shared__ float red[LNF_GROUPS][17];
+    const int e = blockIdx.y;
+    const float* __restrict__ partial = b.partial[e];
+    const int nparts = b.nparts[e], width = 2 * dim;
+    const int cx = threadIdx.x & 15, py = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cx;
+    float a0 = 0.f, a1 = 0.f;
+    if (c < width) {
+        int p = py;
+        for (; p + LNF_GROUPS < nparts; p += 2 * LNF_GROUPS) {
+            a0 += partial[(size_t)p * width + c];
+            a1 += partial[(size_t)(p + LNF_GROUPS) * width + c];
+        }
+        if (p < nparts) a0 += partial[(size_t)p * width + c];
+    }
+    red[py][cx] = a0 + a1;
+    __syncthreads();
+    if (py == 0 && c < width) {
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < LNF_GROUPS; ++k) v += red[k][cx];
+        float* dst = c < dim ? b.dgamma[e] + c : b.dbeta[e] + (c - dim);
+        *dst = b.accumulate[e] ? *dst + v : v;
+    }
+}
+
+extern "C" int vited_layernorm_bwd_finish_batched(int count, const float* const* partial, const int* nparts, float* const* dgamma,
+                                                  float* const* dbeta, const int* accumulate, int64_t dim, void* stream) {
+    if (count < 1 || !partial || !nparts || !dgamma || !dbeta || !accumulate || dim <= 0) return VITED_ERR_BAD_ARG;
+    for (int i0 = 0; i0 < count; i0 += LNF_MAX_BATCH) {
+        const int n = count - i0 < LNF_MAX_BATCH ? count - i0 : LNF_MAX_BATCH;
+        LnFinishBatch b = {};
+        for (int i = 0; i < n; ++i) {
+            if (!partial[i0 + i] || !dgamma[i0 + i] || !dbeta[i0 + i] || nparts[i0 + i] < 1) return VITED_ERR_BAD_ARG;
+            b.partial[i] = partial[i0 + i]; b.dgamma[i] = dgamma[i0 + i]; b.dbeta[i] = dbeta[i0 + i];
+            b.nparts[i] = nparts[i0 + i]; b.accumulate[i] = accumulate[i0 + i];
+        }
+        hipLaunchKernelGGL(ln_bwd_finish_batch_kernel, dim3((unsigned)((2 * dim + 15) / 16), (unsigned)n), dim3(16 * LNF_GROUPS), 0,
+                           (hipStream_t)stream, b, (int)dim);
+    }
+    return vited_check_launch();
+}
+
 static inline int64_t ln_bwd_blocks(int64_t rows) {
     int64_t b = ceil_div64(rows, 8 * 4);  // >= 4 rows per half-wave
     if (b > 768) b = 768;                 // 3 workgroups per CU: measured best of 512 / 768 / 1024 / 1536 / 2048 at 66,560 rows

@@ -573,6 +573,39 @@ class DevicePrefetcher:
 
 
 # ---------------------------------------------------------------------------------------------
+# patch-pair assembly on the device (data/datasets/div2k_patch.py:108-162)
+# ---------------------------------------------------------------------------------------------
+def div2k_pair_plan(u: torch.Tensor, img_size: int, erosion_ratio: float, with_negative: bool = True, train: bool = True):
+    """The random choices of ``DIV2KPatch.__getitem__`` (div2k_patch.py:114-153) for a whole batch at once, from uniform numbers
+    ``u`` [B, 4] in [0, 1) (columns: negative-pair draw, first swap, second swap, erosion):
+      cells  int32 [B, 2]   grid cells (3 columns x 2 rows, row-major) of image 1 and image 2
+      labels fp32  [B, 4]   the 4-bin target (all-zero for the 30 % negatives)
+      erode  int32 [B]      eroded cell size e = ceil(S (1 - r)), r ~ U(erosion_ratio, 2 erosion_ratio) in training
+    first = cell 0, second = 1 (right of it), third = 4 (below second), fourth = 3 (below first), spare = 2."""
+    dev = u.device
+    a, b = u[:, 1] > 0.5, u[:, 2] > 0.5
+    neg = (u[:, 0] < 0.3) if with_negative else torch.zeros_like(a)
+    second = torch.where(neg, torch.where(a, 4, 2), torch.where(a, 3, 1))      # negative: third / spare; positive: fourth / second
+    first = torch.zeros_like(second)
+    img1 = torch.where(b, second, first)
+    img2 = torch.where(b, first, second)
+    cells = torch.stack([img1, img2], dim=1).to(torch.int32)
+    bin_ = a.long() + 2 * b.long()                                              # (a, b) -> label bin 0, 1, 2, 3
+    labels = torch.nn.functional.one_hot(bin_, 4).float() * (~neg).float().unsqueeze(1)
+    r = erosion_ratio * (1.0 + u[:, 3].double()) if train else torch.full_like(u[:, 3], erosion_ratio, dtype=torch.float64)
+    erode = torch.ceil(img_size * (1.0 - r)).to(torch.int32).clamp_(1, img_size)
+    return cells.contiguous(), labels.to(dev), erode.contiguous()
+
+
+def assemble_pairs(regions_u8: torch.Tensor, cells: torch.Tensor, erode: torch.Tensor, img_size: int) -> torch.Tensor:
+    """uint8 regions [B, C, 2 S, 3 S] on the device -> uint8 pairs [B, 2, C, S, S]: erosion crop + Pillow-exact bilinear resize of
+    the two chosen cells in one kernel (``vited_crop_pairs_u8``).  Feed the result straight to the model: ToTensor + Normalize
+    are folded into the patch-embedding kernel."""
+    from . import ops
+    return ops.crop_pairs_u8(regions_u8, cells, erode, img_size)
+
+
+# ---------------------------------------------------------------------------------------------
 # pair mining for the two-stage HisFrag training step (hisfrag.py:117-159, SURVEY.md section 8(f) rank 3)
 # ---------------------------------------------------------------------------------------------
 def mine_pairs(targets: torch.Tensor, neg_per_pos: float = 2.0, generator=None):

@@ -82,6 +82,7 @@ class Runtime:
         self.fused_ln = os.environ.get('VITED_FUSED_LN', '1') != '0'     # LayerNorm inside the neighbouring Linear's kernel (gemm_row.hip)
         self.batch_dw = os.environ.get('VITED_BATCH_DW', '1') != '0'     # a block's weight gradients in one launch (vited_linear_bwd_weight_batched)
         self.dw_queue = None        # inside a block's backward: [(dy, x, dW target, dbias target | None, accumulate)]
+        self.ln_queue = None        # inside a Function's backward: deferred LayerNorm column sums (ops.layernorm_bwd_finish)
         self.tap = None             # test/diagnostic: a dict that receives clones of per-block activations and gradients
         self.block_events = None    # measurement (bench.py): a list that receives (kind, block, 'fwd' | 'bwd', start event, end event)
         self.pinned = False         # a captured hipGraph reads the shadow buffers: never free one, only refresh in place
@@ -296,7 +297,7 @@ def _linear_ln_bwd(rt, dy, h_saved, w, bias, x, gamma, beta, mean, rstd, dx_in=N
         gg, gb = _gtarget(rt, gamma), _gtarget(rt, beta)
         direct = gg is not None and gb is not None
         dx, dx_lp, dg, db = ops.linear_layernorm_bwd(dy, wt, x, gamma, mean, rstd, dx_in=dx_in, dx_out=dx_out, want_lp=want_lp,
-                                                     dgamma=gg if direct else None, dbeta=gb if direct else None)
+                                                     dgamma=gg if direct else None, dbeta=gb if direct else None, defer=rt.ln_queue)
         if direct:
             dg = db = None
     else:
@@ -486,6 +487,7 @@ class EncoderFn(torch.autograd.Function):
         dx = dout.contiguous().view(batch * n, rt.dim).float()
         dx_lp = _lp(rt, dx)
         grads = [None] * len(params)
+        rt.ln_queue = [] if not rt.exact else None
         for i in reversed(range(rt.depth)):
             g1, b1, wqkv, bqkv, wproj, bproj, g2, b2, w1, bb1, w2, bb2 = params[3 + i * nb: 3 + (i + 1) * nb]
             x, sa, xa, sm = ctx.tape[i]
@@ -499,6 +501,9 @@ class EncoderFn(torch.autograd.Function):
             base = 3 + i * nb
             blk = [dg1, db1, dwq, dbq, dwp, dbp, dg2, db2, dw1, dbb1, dw2, dbb2]
             grads[base: base + nb] = blk
+        if rt.ln_queue is not None:
+            ops.layernorm_bwd_finish(rt.ln_queue)       # the encoder's 2 x depth LayerNorm column sums: one launch per 16
+            rt.ln_queue = None
         dpw, dpb, dpos, _ = _patch_tokens_bwd(rt, dx, ctx.patches, pw, pb, pos, with_cls=False, batch=batch)
         grads[0], grads[1], grads[2] = dpw, dpb, dpos
         ctx.tape = ctx.patches = None
@@ -744,6 +749,7 @@ class DecoderFn(torch.autograd.Function):
             dx_lp = dx
         grads[4], grads[5], grads[6], grads[7] = dgN, dbN, dwh, dbh
         dctx = None
+        rt.ln_queue = [] if not rt.exact else None
         for i in reversed(range(rt.c_depth)):
             P = params[ns + i * nb: ns + (i + 1) * nb]
             entry = ctx.tape[i]
@@ -756,6 +762,9 @@ class DecoderFn(torch.autograd.Function):
                 rt.tap[f'dec.dctx.{i}'] = dctx.clone()  # running d(features) after blocks c_depth-1 .. i
             base = ns + i * nb
             grads[base: base + nb] = blk
+        if rt.ln_queue is not None:
+            ops.layernorm_bwd_finish(rt.ln_queue)       # the decoder's 4 x c_depth LayerNorm column sums
+            rt.ln_queue = None
         dpw, dpb, dpos, dcls = _patch_tokens_bwd(rt, dx, ctx.patches, pw, pb, pos, with_cls=True, batch=batch)
         grads[0], grads[1], grads[2], grads[3] = dpw, dpb, dpos, dcls.view_as(cls)
         dfeats = dctx.view(batch, rt.n1, d) if ctx.feats_needs_grad and dctx is not None else None

@@ -153,6 +153,23 @@ def patchify(img: torch.Tensor, patch: int, dtype: torch.dtype, batch_index: tor
     return out
 
 
+def crop_pairs_u8(regions: torch.Tensor, cells: torch.Tensor, erode: torch.Tensor, img_size: int) -> torch.Tensor:
+    """regions uint8 [B, C, 2 S, 3 S] (any batch stride), cells int32 [B, 2], erode int32 [B] -> uint8 [B, 2, C, S, S]: the pair
+    of eroded grid cells resized back to S x S (``vited_crop_pairs_u8``; div2k_patch.py:108-121,155-162)."""
+    _need_gpu(regions, cells, erode)
+    s = int(img_size)
+    assert regions.dtype == torch.uint8 and regions.dim() == 4 and regions.shape[2] == 2 * s and regions.shape[3] == 3 * s
+    b, c = regions.shape[:2]
+    if regions.stride()[1:] != (6 * s * s, 3 * s, 1):
+        regions = regions.contiguous()
+    assert cells.dtype == torch.int32 and cells.shape == (b, 2) and cells.is_contiguous()
+    assert erode.dtype == torch.int32 and erode.shape == (b,) and erode.is_contiguous()
+    out = torch.empty((b, 2, c, s, s), dtype=torch.uint8, device=regions.device)
+    _lib.check(_lib.load().vited_crop_pairs_u8(_ptr(regions), regions.stride(0), _ptr(cells), _ptr(erode), _ptr(out), b, c, s, _stream()),
+               'vited_crop_pairs_u8')
+    return out
+
+
 def slice_rows_cast(x: torch.Tensor, row_offset: int, rows: int, dtype: torch.dtype) -> torch.Tensor:
     """fp32 [B, R, D] -> dtype [B * rows, D] taking rows [row_offset, row_offset + rows) of every batch."""
     _need_gpu(x)
@@ -371,10 +388,13 @@ def linear_residual_layernorm_fwd(a, w, bias, residual, gamma=None, beta=None, e
     return y, h, mean, rstd
 
 
-def linear_layernorm_bwd(dy, wt, x, gamma, mean, rstd, dx_in=None, dx_out=None, want_lp: bool = False, dgamma=None, dbeta=None):
+def linear_layernorm_bwd(dy, wt, x, gamma, mean, rstd, dx_in=None, dx_out=None, want_lp: bool = False, dgamma=None, dbeta=None,
+                         defer=None):
     """dx = (dx_in or 0) + LN'(dy wt^T; x, mean, rstd, gamma) in one kernel (``vited_linear_layernorm_bwd``): the input
     gradient of ``y = LayerNorm(x) W^T`` without materialising d(LayerNorm output).  ``wt`` = the transposed weight shadow
-    [N, K].  Returns (dx fp32, dx_lp bf16 | None, dgamma, dbeta); given ``dgamma`` / ``dbeta`` are ADDED onto."""
+    [N, K].  Returns (dx fp32, dx_lp bf16 | None, dgamma, dbeta); given ``dgamma`` / ``dbeta`` are ADDED onto.
+    ``defer`` (a list): the column sums are NOT finished here - (partials, rows, dgamma, dbeta, accumulate) is appended and
+    ``layernorm_bwd_finish(defer)`` later finishes many LayerNorms with one launch."""
     _need_gpu(dy, wt, x, gamma, mean, rstd, dx_in, dx_out)
     assert dy.dtype == wt.dtype == torch.bfloat16 and x.dtype == torch.float32
     lddy, ldwt, ldx = _rows2d(dy), _rows2d(wt), _rows2d(x)
@@ -391,12 +411,32 @@ def linear_layernorm_bwd(dy, wt, x, gamma, mean, rstd, dx_in=None, dx_out=None, 
     else:
         dgamma = torch.empty(n, dtype=torch.float32, device=x.device)
         dbeta = torch.empty(n, dtype=torch.float32, device=x.device)
-    ws = workspace(lib.vited_linear_layernorm_bwd_workspace_bytes(m, n), x.device)
+    if defer is not None:
+        rows = int(lib.vited_linear_layernorm_bwd_partial_rows(m))
+        ws = torch.empty(rows * 2 * n, dtype=torch.float32, device=x.device)     # lives until the flush
+        defer.append((ws, rows, dgamma, dbeta, accumulate))
+    else:
+        ws = workspace(lib.vited_linear_layernorm_bwd_workspace_bytes(m, n), x.device)
     _lib.check(lib.vited_linear_layernorm_bwd(
         _ptr(dy), lddy, _ptr(wt), ldwt, _ptr(x), ldx, _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dx_in),
-        _rows2d(dx_in) if dx_in is not None else 0, _ptr(dx_out), _rows2d(dx_out), _ptr(dx_lp), n, _ptr(dgamma), _ptr(dbeta),
+        _rows2d(dx_in) if dx_in is not None else 0, _ptr(dx_out), _rows2d(dx_out), _ptr(dx_lp), n,
+        0 if defer is not None else _ptr(dgamma), 0 if defer is not None else _ptr(dbeta),
         int(accumulate), m, n, k, _ptr(ws), ws.numel() * 4, _stream()), 'vited_linear_layernorm_bwd')
     return dx_out, dx_lp, dgamma, dbeta
+
+
+def layernorm_bwd_finish(entries):
+    """Finish the deferred column sums of ``linear_layernorm_bwd(..., defer=entries)``: one launch per 16 LayerNorms."""
+    import ctypes as C
+    n = len(entries)
+    if not n:
+        return
+    vp, ci = C.c_void_p * n, C.c_int * n
+    dim = entries[0][2].numel()
+    _lib.check(_lib.load().vited_layernorm_bwd_finish_batched(
+        n, vp(*[e[0].data_ptr() for e in entries]), ci(*[e[1] for e in entries]), vp(*[e[2].data_ptr() for e in entries]),
+        vp(*[e[3].data_ptr() for e in entries]), ci(*[int(e[4]) for e in entries]), dim, _stream()), 'vited_layernorm_bwd_finish_batched')
+    entries.clear()
 
 
 # ---------------------------------------------------------------------------------------------
