@@ -208,6 +208,20 @@ int vited_linear_layernorm_bwd(const void* dy, int64_t lddy, const void* wt, int
                                float* dgamma, float* dbeta, int accumulate, int64_t M, int64_t N, int64_t K,
                                float* workspace, int64_t workspace_bytes, void* stream);
 
+/* ---- norm_context + kv projection of all decoder blocks as one GEMM (context_fold.hip) ----
+ * Every CrossBlock normalises the SAME encoder features with its own norm_context (vision_transformer.py:245,269-270) before
+ * its kv projection (:152,177-179).  With xhat = LayerNorm(features; 1, 0):  kv_l = xhat (W_l o gamma_l)^T + (W_l beta_l + b_l).
+ * vited_fold_context_weights writes the folded bf16 weights of `count` (<= 16) blocks stacked [count * N, K], their transpose
+ * [K, count * N] and the folded fp32 bias [count * N]; vited_unfold_context_grads turns the gradient of the folded weights /
+ * bias (dwf [count * N, K], dbf [count * N], fp32) back into dW_l, db_l (may be null), dgamma_l, dbeta_l - overwritten, or added
+ * when accumulate != 0.  Pointer arrays are host arrays of device pointers. */
+int vited_fold_context_weights(int count, const float* const* w, const float* const* bias, const float* const* gamma,
+                               const float* const* beta, int64_t N, int64_t K, void* w_out, void* wt_out, float* bias_out,
+                               void* stream);
+int vited_unfold_context_grads(int count, const float* dwf, const float* dbf, const float* const* w, const float* const* gamma,
+                               float* const* dw, float* const* dbias, float* const* dgamma, float* const* dbeta, int64_t N,
+                               int64_t K, int accumulate, void* stream);
+
 /* ---- fused MLP branch of a block: y = x + fc2(gelu(fc1(LayerNorm(x)))) (vision_transformer.py:126,271; timm Mlp :115,:259) ---- */
 
 /* One kernel for the second half of Block.forward / CrossBlock.forward (SURVEY.md section 8(b) "optional fused mlp"): LayerNorm

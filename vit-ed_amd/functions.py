@@ -83,6 +83,9 @@ class Runtime:
         self.batch_dw = os.environ.get('VITED_BATCH_DW', '1') != '0'     # a block's weight gradients in one launch (vited_linear_bwd_weight_batched)
         self.dw_queue = None        # inside a block's backward: [(dy, x, dW target, dbias target | None, accumulate)]
         self.ln_queue = None        # inside a Function's backward: deferred LayerNorm column sums (ops.layernorm_bwd_finish)
+        self.fold_context = os.environ.get('VITED_FOLD_CONTEXT', '1') != '0'   # norm_context + kv of all decoder blocks as one GEMM
+        self._fold_bufs = None      # (folded W [L 2D, D], its transpose, folded bias): refreshed in place every forward
+        self._unit_ln = None        # (ones, zeros) for the affine-free LayerNorm of the features
         self.tap = None             # test/diagnostic: a dict that receives clones of per-block activations and gradients
         self.block_events = None    # measurement (bench.py): a list that receives (kind, block, 'fwd' | 'bwd', start event, end event)
         self.pinned = False         # a captured hipGraph reads the shadow buffers: never free one, only refresh in place
@@ -597,7 +600,7 @@ def _dense_rows(t):
     return out
 
 
-def _dec_block_fwd(rt, x, ctxf, P, batch, n, grad, cls_only, index=0, ln1=None, next_ln=None):
+def _dec_block_fwd(rt, x, ctxf, P, batch, n, grad, cls_only, index=0, ln1=None, next_ln=None, kv3=None):
     """One CrossBlock forward (vision_transformer.py:268-272).  ``cls_only`` (the LAST decoder block): only x[:, 0] of the
     block's output reaches the head (:400, :417 - the final norm and the head are row-wise), and within a CrossBlock the
     token rows only mix in the self-attention, as keys / values.  So after the block's qkv projection everything runs on the
@@ -623,10 +626,14 @@ def _dec_block_fwd(rt, x, ctxf, P, batch, n, grad, cls_only, index=0, ln1=None, 
         nq = 1
     # cross attention: q from image-2 tokens, k/v from image-1 features (:174-200)
     hq, mq, rq = lnq
-    hc, mc, rc = ops.layernorm_fwd(ctxf, gx, bx, LN_EPS, rt.act_dtype)
     q = ops.gemm(hq, rt.weight(wq), bias=bq)
-    kv = ops.gemm(hc, rt.weight(wkv), bias=bkv)                      # [Mc, 2D], columns [2][h][hd] (:178)
-    kv3 = kv.view(batch, rt.n1, 2 * d)
+    if kv3 is None:
+        hc, mc, rc = ops.layernorm_fwd(ctxf, gx, bx, LN_EPS, rt.act_dtype)
+        kv = ops.gemm(hc, rt.weight(wkv), bias=bkv)                  # [Mc, 2D], columns [2][h][hd] (:178)
+        kv3 = kv.view(batch, rt.n1, 2 * d)
+    else:
+        hc = mc = rc = None     # this block's keys / values came out of the folded all-blocks GEMM (_context_kv_folded): a strided view
+        kv = kv3
     oc, lse_c = ops.attention_fwd(q.view(batch, nq, d), kv3[:, :, 0:d], kv3[:, :, d:2 * d], rt.heads, rt.scale)
     if rt.keep_attn:
         _keep_attention(rt, ('cross_blocks', index, 'cross_attn'), q.view(batch, nq, d), kv3[:, :, 0:d])
@@ -638,7 +645,7 @@ def _dec_block_fwd(rt, x, ctxf, P, batch, n, grad, cls_only, index=0, ln1=None, 
     return xc, entry, nxt
 
 
-def _dec_block_bwd(rt, dx, dx_lp, ctxf, dctx, P, entry, batch, n, cls_only, tap_index):
+def _dec_block_bwd(rt, dx, dx_lp, ctxf, dctx, P, entry, batch, n, cls_only, tap_index, dkv3=None):
     """Backward of _dec_block_fwd.  dx / dx_lp: gradient w.r.t. the block's output (all rows, or the cls rows when cls_only).
     Returns (d input fp32, its low-precision copy, d context (accumulated in place), the 22 parameter gradients)."""
     g1, b1, wqkv, bqkv, wproj, bproj, gc, bc, gx, bx, wq, bq, wkv, bkv, wcp, bcp, g2, b2, w1, bb1, w2, bb2 = P
@@ -650,8 +657,12 @@ def _dec_block_bwd(rt, dx, dx_lp, ctxf, dctx, P, entry, batch, n, cls_only, tap_
     # cross attention
     doc, dwcp, dbcp = _linear_bwd(rt, dx_lp, oc, wcp, bcp)
     dq = torch.empty_like(q)
-    dkv = torch.empty_like(kv)
-    kv3, dkv3 = kv.view(batch, rt.n1, 2 * d), dkv.view(batch, rt.n1, 2 * d)
+    folded = hc is None
+    if folded:
+        kv3, dkv = kv, dkv3                 # views of the all-blocks kv / d(kv) tensors
+    else:
+        dkv = torch.empty_like(kv)
+        kv3, dkv3 = kv.view(batch, rt.n1, 2 * d), dkv.view(batch, rt.n1, 2 * d)
     if rt.keep_attn:
         _keep_attention_grad(rt, ('cross_blocks', tap_index, 'cross_attn'), doc.view(batch, nq, d), kv3[:, :, d:2 * d])
     ops.attention_bwd(q.view(batch, nq, d), kv3[:, :, 0:d], kv3[:, :, d:2 * d], oc.view(batch, nq, d),
@@ -665,8 +676,11 @@ def _dec_block_bwd(rt, dx, dx_lp, ctxf, dctx, P, entry, batch, n, cls_only, tap_
     dx, dx_lp, dgc, dbc, dwq, dbq = _linear_ln_bwd(rt, dq, hq, wq, bq, xa, gc, bc, mq, rq, dx_in=dx)
     if rt.exact:
         dx_lp = dx
-    # d(context) accumulates over the c_depth blocks in fp32, in place
-    dctx, _, dgx, dbx, dwkv, dbkv = _linear_ln_bwd(rt, dkv, hc, wkv, bkv, ctxf, gx, bx, mc, rc, dx_in=dctx, dx_out=dctx, want_lp=False)
+    if folded:
+        dgx = dbx = dwkv = dbkv = None      # filled in by _context_kv_folded_bwd once every block has written its d(kv)
+    else:
+        # d(context) accumulates over the c_depth blocks in fp32, in place
+        dctx, _, dgx, dbx, dwkv, dbkv = _linear_ln_bwd(rt, dkv, hc, wkv, bkv, ctxf, gx, bx, mc, rc, dx_in=dctx, dx_out=dctx, want_lp=False)
     if not cls_only:
         dx, dx_lp, (dg1, db1, dwqkv, dbqkv, dwp, dbp) = _attn_branch_bwd(rt, dx, dx_lp, x, g1, b1, wqkv, bqkv, wproj, bproj, sa, batch, n,
                                                                            key=('cross_blocks', tap_index, 'attn'))
@@ -687,6 +701,50 @@ def _dec_block_bwd(rt, dx, dx_lp, ctxf, dctx, P, entry, batch, n, cls_only, tap_
                              dg2, db2, dw1, dbb1, dw2, dbb2]
 
 
+def _context_kv_folded(rt, ctxf, blocks):
+    """Keys / values of EVERY decoder block from one LayerNorm and one GEMM (csrc/context_fold.hip): xhat = LayerNorm(features; 1, 0),
+    kv_all = xhat W'^T + b' with W'_l = W_l o gamma_l, b'_l = b_l + W_l beta_l stacked over the blocks.
+    Returns (kv_all [Mc, L 2D], (xhat, mean, rstd), folded buffers)."""
+    dev = ctxf.device
+    if rt._unit_ln is None or rt._unit_ln[0].device != dev:
+        rt._unit_ln = (torch.ones(rt.dim, dtype=torch.float32, device=dev), torch.zeros(rt.dim, dtype=torch.float32, device=dev))
+    ws, bs, gs, bes = [P[12] for P in blocks], [P[13] for P in blocks], [P[8] for P in blocks], [P[9] for P in blocks]
+    bufs = rt._fold_bufs
+    if bufs is not None and (bufs[0].shape[0] != len(blocks) * 2 * rt.dim or bufs[0].device != dev):
+        if rt.pinned:
+            rt._retired.append(bufs)        # a captured graph still reads them
+        bufs = None
+    rt._fold_bufs = bufs = ops.fold_context_weights([w.detach() for w in ws], [b.detach() if b is not None else None for b in bs],
+                                                    [g.detach() for g in gs], [b.detach() for b in bes], out=bufs)
+    xhat, mean, rstd = ops.layernorm_fwd(ctxf, rt._unit_ln[0], rt._unit_ln[1], LN_EPS, rt.act_dtype)
+    kv_all = ops.gemm(xhat, bufs[0], bias=bufs[2])
+    return kv_all, (xhat, mean, rstd), bufs
+
+
+def _context_kv_folded_bwd(rt, dkv_all, ctxf, saved, bufs, blocks):
+    """Backward of _context_kv_folded once every block has written its d(kv) slice: d(features) from ONE row-complete kernel
+    (input-gradient GEMM with K = L 2D + the affine-free LayerNorm's backward), the folded weights' gradient from one
+    weight-gradient GEMM, unfolded into dW_kv, db_kv, d(norm_context.weight / bias) of every block.
+    Returns (d features fp32, [(dgx, dbx, dwkv, dbkv) per block] - None entries when accumulated straight into .grad)."""
+    xhat, mean, rstd = saved
+    ones = rt._unit_ln[0]
+    if _row_kernel_ok(rt, dkv_all.shape[0], bufs[1].shape[0], dkv_all.shape[1], dkv_all.dtype, dkv_all, ctxf):
+        dctx, _, _, _ = ops.linear_layernorm_bwd(dkv_all, bufs[1], ctxf, ones, mean, rstd)
+    else:
+        dh = ops.gemm(dkv_all, bufs[1])
+        dctx, _, _, _ = ops.layernorm_bwd(dh, ctxf, ones, mean, rstd)
+    dwf, dbf = ops.linear_bwd_weight(dkv_all, xhat)
+    ws, bs, gs, bes = [P[12] for P in blocks], [P[13] for P in blocks], [P[8] for P in blocks], [P[9] for P in blocks]
+    targets = [(_gtarget(rt, w), _gtarget(rt, b) if b is not None else None, _gtarget(rt, g), _gtarget(rt, be)) for w, b, g, be in zip(ws, bs, gs, bes)]
+    direct = all(t[0] is not None and t[2] is not None and t[3] is not None and (b is None or t[1] is not None) for t, b in zip(targets, bs))
+    if not direct:
+        targets = [(torch.empty_like(w), torch.empty_like(b) if b is not None else None, torch.empty_like(g), torch.empty_like(be))
+                   for w, b, g, be in zip(ws, bs, gs, bes)]
+    ops.unfold_context_grads(dwf, dbf, [w.detach() for w in ws], [g.detach() for g in gs], [t[0] for t in targets], [t[1] for t in targets],
+                             [t[2] for t in targets], [t[3] for t in targets], accumulate=direct)
+    return dctx, [(None, None, None, None) if direct else (t[2], t[3], t[0], t[1]) for t in targets]
+
+
 class DecoderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rt: Runtime, feats, img2, img2_index, *params):
@@ -702,9 +760,15 @@ class DecoderFn(torch.autograd.Function):
         d = rt.dim
         cls_tail = rt.cls_tail and rt.c_depth > 0 and not rt.keep_attn    # the visualisation path wants every query row's map
         ln1 = None
+        fold = rt.fold_context and not rt.exact and rt.c_depth > 1 and rt.c_depth <= ops.MAX_FOLDED_BLOCKS and rt.dim % 32 == 0
+        kv_all = kv_saved = fold_bufs = None
+        if fold:
+            kv_all, kv_saved, fold_bufs = _context_kv_folded(rt, ctxf, blocks)
+            kv_all3 = kv_all.view(batch, rt.n1, rt.c_depth * 2 * d)
         for i, P in enumerate(blocks):
             nxt = (blocks[i + 1][0], blocks[i + 1][1]) if i + 1 < rt.c_depth else None     # the next block's norm1
-            x, entry, ln1 = _dec_block_fwd(rt, x, ctxf, P, batch, n, grad, cls_tail and i == rt.c_depth - 1, index=i, ln1=ln1, next_ln=nxt)
+            x, entry, ln1 = _dec_block_fwd(rt, x, ctxf, P, batch, n, grad, cls_tail and i == rt.c_depth - 1, index=i, ln1=ln1, next_ln=nxt,
+                                           kv3=kv_all3[:, :, i * 2 * d:(i + 1) * 2 * d] if fold else None)
             if grad:
                 tape.append(entry)
             if rt.tap is not None:
@@ -717,6 +781,7 @@ class DecoderFn(torch.autograd.Function):
             ctx.rt, ctx.tape, ctx.patches, ctx.batch, ctx.params = rt, tape, patches, batch, params
             ctx.ctxf, ctx.final, ctx.cls_tail = ctxf, (xcls, y, mN, rN), cls_tail
             ctx.feats_needs_grad = feats.requires_grad
+            ctx.fold = (kv_all, kv_saved, fold_bufs) if fold else None
         return logits
 
     @staticmethod
@@ -750,18 +815,31 @@ class DecoderFn(torch.autograd.Function):
         grads[4], grads[5], grads[6], grads[7] = dgN, dbN, dwh, dbh
         dctx = None
         rt.ln_queue = [] if not rt.exact else None
+        dkv_all3 = None
+        if ctx.fold is not None:
+            dkv_all = torch.empty_like(ctx.fold[0])
+            dkv_all3 = dkv_all.view(batch, rt.n1, rt.c_depth * 2 * d)
         for i in reversed(range(rt.c_depth)):
             P = params[ns + i * nb: ns + (i + 1) * nb]
             entry = ctx.tape[i]
             ctx.tape[i] = None
             with _DwBatch(rt):
                 dx, dx_lp, dctx, blk = _dec_block_bwd(rt, dx, dx_lp, ctx.ctxf, dctx, P, entry, batch, n,
-                                                      ctx.cls_tail and i == rt.c_depth - 1, i)
+                                                      ctx.cls_tail and i == rt.c_depth - 1, i,
+                                                      dkv3=dkv_all3[:, :, i * 2 * d:(i + 1) * 2 * d] if dkv_all3 is not None else None)
             if rt.tap is not None:
                 rt.tap[f'dec.dx.{i}'] = dx.clone()      # gradient w.r.t. the INPUT of decoder block i
-                rt.tap[f'dec.dctx.{i}'] = dctx.clone()  # running d(features) after blocks c_depth-1 .. i
+                if dctx is not None:
+                    rt.tap[f'dec.dctx.{i}'] = dctx.clone()  # running d(features) after blocks c_depth-1 .. i
             base = ns + i * nb
             grads[base: base + nb] = blk
+        if ctx.fold is not None:
+            blocks = [params[ns + i * nb: ns + (i + 1) * nb] for i in range(rt.c_depth)]
+            dctx, per_block = _context_kv_folded_bwd(rt, dkv_all, ctx.ctxf, ctx.fold[1], ctx.fold[2], blocks)
+            for i, (dgx, dbx, dwkv, dbkv) in enumerate(per_block):
+                base = ns + i * nb
+                grads[base + 8], grads[base + 9], grads[base + 12], grads[base + 13] = dgx, dbx, dwkv, dbkv
+            ctx.fold = None
         if rt.ln_queue is not None:
             ops.layernorm_bwd_finish(rt.ln_queue)       # the decoder's 4 x c_depth LayerNorm column sums
             rt.ln_queue = None

@@ -440,6 +440,45 @@ def layernorm_bwd_finish(entries):
 
 
 # ---------------------------------------------------------------------------------------------
+MAX_FOLDED_BLOCKS = 16
+
+
+def fold_context_weights(ws, biases, gammas, betas, out=None):
+    """Folded kv weights of several decoder blocks: W'_l = W_l o gamma_l (bf16, stacked [L N, K] and transposed [K, L N]) and
+    b'_l = b_l + W_l beta_l (fp32 [L N]) - ``vited_fold_context_weights``.  ``out`` = (w, wt, b) buffers to refresh in place."""
+    import ctypes as C
+    n_blk = len(ws)
+    _need_gpu(*ws, *gammas, *betas)
+    n, k = ws[0].shape
+    dev = ws[0].device
+    if out is None:
+        out = (torch.empty((n_blk * n, k), dtype=torch.bfloat16, device=dev), torch.empty((k, n_blk * n), dtype=torch.bfloat16, device=dev),
+               torch.empty(n_blk * n, dtype=torch.float32, device=dev))
+    vp = C.c_void_p * n_blk
+    for t in list(ws) + list(gammas) + list(betas):
+        assert t.dtype == torch.float32 and t.is_contiguous()
+    _lib.check(_lib.load().vited_fold_context_weights(n_blk, vp(*[w.data_ptr() for w in ws]), vp(*[_ptr(b) or None for b in biases]),
+                                                      vp(*[g.data_ptr() for g in gammas]), vp(*[b.data_ptr() for b in betas]), n, k,
+                                                      _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), _stream()), 'vited_fold_context_weights')
+    return out
+
+
+def unfold_context_grads(dwf, dbf, ws, gammas, dws, dbiases, dgammas, dbetas, accumulate: bool):
+    """Gradients of the folded weights / bias -> dW_l, db_l, dgamma_l, dbeta_l (``vited_unfold_context_grads``)."""
+    import ctypes as C
+    n_blk = len(ws)
+    n, k = ws[0].shape
+    assert dwf.dtype == dbf.dtype == torch.float32 and dwf.is_contiguous() and dbf.is_contiguous()
+    assert dwf.shape == (n_blk * n, k) and dbf.numel() == n_blk * n
+    vp = C.c_void_p * n_blk
+    _lib.check(_lib.load().vited_unfold_context_grads(n_blk, _ptr(dwf), _ptr(dbf), vp(*[w.data_ptr() for w in ws]),
+                                                      vp(*[g.data_ptr() for g in gammas]), vp(*[t.data_ptr() for t in dws]),
+                                                      vp(*[_ptr(t) or None for t in dbiases]), vp(*[t.data_ptr() for t in dgammas]),
+                                                      vp(*[t.data_ptr() for t in dbetas]), n, k, int(bool(accumulate)), _stream()),
+               'vited_unfold_context_grads')
+
+
+# ---------------------------------------------------------------------------------------------
 def mlp_fused_supported(x: torch.Tensor, w1: torch.Tensor) -> bool:
     """The fused MLP kernel covers bf16, embed dim 384, hidden 1536 (every shipped pjs config)."""
     return w1.dtype == torch.bfloat16 and tuple(w1.shape) == (1536, 384) and x.shape[-1] == 384
