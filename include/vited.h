@@ -198,6 +198,15 @@ int vited_linear_residual_layernorm_fwd(const void* a, int64_t lda, const void* 
  * dgamma / dbeta: column sums of dh * xhat / dh, overwritten or (accumulate != 0) added.  workspace >= *_workspace_bytes.
  * With dgamma == dbeta == null the column partials stay in `workspace` as [vited_linear_layernorm_bwd_partial_rows(M)][2][N]
  * fp32 for vited_layernorm_bwd_finish_batched, which sums the partials of several LayerNorms in one launch. */
+/* The same with the contraction dim cut into `segments` column blocks of seg_k, block j read from the tensor at
+ * dy + j * seg_stride (elements): one [M, seg_k] tensor per decoder block (each contiguous for its own attention backward), all
+ * contracted against wt [N, segments * seg_k] in one kernel. */
+int vited_linear_layernorm_bwd_segmented(const void* dy, int64_t lddy, int64_t seg_k, int64_t seg_stride, int64_t segments,
+                                         const void* wt, int64_t ldwt, const float* x, int64_t ldx, const float* gamma,
+                                         const float* mean, const float* rstd, const float* dx_in, int64_t dx_in_ld,
+                                         float* dx_out, int64_t dx_out_ld, void* dx_lp, int64_t dx_lp_ld, float* dgamma,
+                                         float* dbeta, int accumulate, int64_t M, int64_t N, float* workspace,
+                                         int64_t workspace_bytes, void* stream);
 int64_t vited_linear_layernorm_bwd_partial_rows(int64_t M);
 int vited_layernorm_bwd_finish_batched(int count, const float* const* partial, const int* nparts, float* const* dgamma,
                                        float* const* dbeta, const int* accumulate, int64_t dim, void* stream);

@@ -564,3 +564,49 @@ def test_cross_block_fwd_matches_the_oracle_block(vited, gpu, batch, tokens, ctx
                                   bf(ca.kv.weight), g(ca.kv.bias), bf(ca.proj.weight), g(ca.proj.bias), ln(blk.norm2),
                                   bf(blk.mlp.fc1.weight), g(blk.mlp.fc1.bias), bf(blk.mlp.fc2.weight), g(blk.mlp.fc2.bias))
     torch.testing.assert_close(y.cpu(), want, rtol=3e-2, atol=3e-2)
+
+
+def test_context_fold_unfold_and_segmented_backward(vited, gpu):
+    """csrc/context_fold.hip + the segmented row-complete backward: norm_context + kv of L decoder blocks through folded
+    weights.  kv_l = LN(x; g_l, b_l) W_l^T + c_l must equal xhat (W_l o g_l)^T + (W_l b_l + c_l); the gradients that come back
+    through the folded weights (unfold) and the one-kernel d(features) over L separate d(kv) tensors are compared with fp64
+    autograd through the unfolded formulation."""
+    ops = vited.ops
+    L, D, N2, M = 3, 384, 768, 1000
+    ws = [_rand((N2, D), gpu, 10 + l, 0.05) for l in range(L)]
+    cs = [_rand((N2,), gpu, 20 + l, 0.1) for l in range(L)]
+    gs = [1.0 + _rand((D,), gpu, 30 + l, 0.2) for l in range(L)]
+    bs = [_rand((D,), gpu, 40 + l, 0.2) for l in range(L)]
+    wf, wft, bf = ops.fold_context_weights(ws, cs, gs, bs)
+    for l in range(L):
+        want = (ws[l] * gs[l][None, :]).to(torch.bfloat16)
+        assert torch.equal(wf[l * N2:(l + 1) * N2], want) and torch.equal(wft[:, l * N2:(l + 1) * N2], want.t())
+        torch.testing.assert_close(bf[l * N2:(l + 1) * N2], cs[l] + ws[l] @ bs[l], rtol=1e-5, atol=1e-5)
+    # forward equivalence in fp64 (the fold is exact algebra)
+    x = _rand((M, D), gpu, 50, 1.5) + 0.2
+    xd = x.double().requires_grad_(True)
+    prm = [[t.double().requires_grad_(True) for t in (ws[l], cs[l], gs[l], bs[l])] for l in range(L)]
+    dkv = torch.stack([_rand((M, N2), gpu, 60 + l, 1.0, torch.bfloat16) for l in range(L)])          # [L, M, N2]
+    outs = [F.linear(F.layer_norm(xd, (D,), g, b, 1e-6), w, c) for w, c, g, b in prm]
+    torch.autograd.backward(outs, [dkv[l].double() for l in range(L)])
+    mu, var = x.double().mean(1), x.double().var(1, unbiased=False)
+    xhat = ((x.double() - mu[:, None]) * (var[:, None] + 1e-6).rsqrt())
+    torch.testing.assert_close(xhat @ (ws[0].double() * gs[0].double()).t() + (cs[0].double() + ws[0].double() @ bs[0].double()),
+                               outs[0].detach(), rtol=1e-9, atol=1e-9)
+    # d(features): ONE kernel contracting over the L separate d(kv) tensors against the transposed folded weights
+    mean, rstd = mu.float(), (var + 1e-6).rsqrt().float()
+    ones = torch.ones(D, device=gpu)
+    dx, _, _, _ = ops.linear_layernorm_bwd(dkv, wft, x, ones, mean, rstd)
+    torch.testing.assert_close(dx.double(), xd.grad, rtol=2e-2, atol=2e-2 * float(xd.grad.abs().max()))       # bf16 folded weights
+    dx_cat, _, _, _ = ops.linear_layernorm_bwd(dkv.permute(1, 0, 2).reshape(M, L * N2).contiguous(), wft, x, ones, mean, rstd)
+    assert torch.equal(dx, dx_cat), 'segmented operand != the same columns as one tensor'
+    # unfold: gradients of the folded weights / bias -> dW, dc, dgamma, dbeta per block
+    dwf = torch.cat([dkv[l].double().t() @ xhat for l in range(L)]).float()
+    dbf = torch.cat([dkv[l].double().sum(0) for l in range(L)]).float()
+    for accumulate in (False, True):
+        tgt = [[torch.full_like(t, 0.5 if accumulate else float('nan')) for t in (ws[l], cs[l], gs[l], bs[l])] for l in range(L)]
+        ops.unfold_context_grads(dwf, dbf, ws, gs, [t[0] for t in tgt], [t[1] for t in tgt], [t[2] for t in tgt], [t[3] for t in tgt], accumulate)
+        base = 0.5 if accumulate else 0.0
+        for l in range(L):
+            for got, ref in zip(tgt[l], prm[l]):
+                torch.testing.assert_close(got.double() - base, ref.grad, rtol=1e-3, atol=1e-3 * float(ref.grad.abs().max()))

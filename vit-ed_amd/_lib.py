@@ -49,6 +49,8 @@ SIGNATURES = {
     'vited_linear_bwd_weight_batched': (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _i64, _p]),
     'vited_linear_layernorm_supported': (_i, [_i64, _i64, _i64]),
     'vited_linear_residual_layernorm_fwd': (_i, [_p, _i64, _p, _i64, _p, _p, _i64, _p, _i64, _p, _p, _f, _p, _i64, _p, _p, _i64, _i64, _i64, _p]),
+    'vited_linear_layernorm_bwd_segmented': (_i, [_p, _i64, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _p, _p, _p, _i64, _p, _i64, _p, _i64, _p, _p,
+                                                  _i, _i64, _i64, _p, _i64, _p]),
     'vited_linear_layernorm_bwd_partial_rows': (_i64, [_i64]),
     'vited_layernorm_bwd_finish_batched': (_i, [_i, _p, _p, _p, _p, _p, _i64, _p]),
     'vited_linear_layernorm_bwd_workspace_bytes': (_i64, [_i64, _i64]),

@@ -74,9 +74,11 @@ struct UnfoldArgs {
     int count, N, K, accumulate;
 };
 
-// block = (l, 64 columns k): 256 threads = 64 columns x 4 row groups; column sums over n combined through LDS
-__global__ void __launch_bounds__(256) unfold_context_kernel(const UnfoldArgs a) {
-    __shared__ float red[2][4][64];
+// block = (l, 64 columns k): 1024 threads = 64 columns x 16 row groups (48 rows each at N = 768: the loads of a thread are
+// independent, 4 in flight); column sums over n combined through LDS
+#define UF_GROUPS 16
+__global__ void __launch_bounds__(64 * UF_GROUPS) unfold_context_kernel(const UnfoldArgs a) {
+    __shared__ float red[2][UF_GROUPS][64];
     const int l = blockIdx.y, kx = threadIdx.x & 63, ng = threadIdx.x >> 6;
     const int k = blockIdx.x * 64 + kx;
     const bool ok = k < a.K;
@@ -86,7 +88,8 @@ __global__ void __launch_bounds__(256) unfold_context_kernel(const UnfoldArgs a)
     float* __restrict__ dw = a.dw[l];
     const float g = ok ? a.gamma[l][k] : 0.f;
     float sg = 0.f, sb = 0.f;
-    for (int n = ng; n < a.N; n += 4) {
+#pragma unroll 4
+    for (int n = ng; n < a.N; n += UF_GROUPS) {
         if (ok) {
             const int64_t o = (int64_t)n * a.K + k;
             const float d = dwf[o], wv = w[o];
@@ -99,13 +102,17 @@ __global__ void __launch_bounds__(256) unfold_context_kernel(const UnfoldArgs a)
     red[1][ng][kx] = sb;
     __syncthreads();
     if (ng == 0 && ok) {
-        const float tg = (red[0][0][kx] + red[0][1][kx]) + (red[0][2][kx] + red[0][3][kx]);
-        const float tb = (red[1][0][kx] + red[1][1][kx]) + (red[1][2][kx] + red[1][3][kx]);
+        float tg = 0.f, tb = 0.f;
+#pragma unroll
+        for (int w = 0; w < UF_GROUPS; ++w) {
+            tg += red[0][w][kx];
+            tb += red[1][w][kx];
+        }
         a.dgamma[l][k] = a.accumulate ? a.dgamma[l][k] + tg : tg;
         a.dbeta[l][k] = a.accumulate ? a.dbeta[l][k] + tb : tb;
     }
     if (blockIdx.x == 0 && a.dbias[l]) {
-        for (int n = threadIdx.x; n < a.N; n += 256) a.dbias[l][n] = a.accumulate ? a.dbias[l][n] + dbf[n] : dbf[n];
+        for (int n = threadIdx.x; n < a.N; n += 64 * UF_GROUPS) a.dbias[l][n] = a.accumulate ? a.dbias[l][n] + dbf[n] : dbf[n];
     }
 }
 
@@ -120,6 +127,6 @@ extern "C" int vited_unfold_context_grads(int count, const float* dwf, const flo
         a.w[i] = w[i]; a.gamma[i] = gamma[i]; a.dw[i] = dw[i]; a.dbias[i] = dbias[i]; a.dgamma[i] = dgamma[i]; a.dbeta[i] = dbeta[i];
     }
     a.dwf = dwf; a.dbf = dbf; a.count = count; a.N = (int)N; a.K = (int)K; a.accumulate = accumulate;
-    hipLaunchKernelGGL(unfold_context_kernel, dim3((unsigned)ceil_div64(K, 64), (unsigned)count), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(unfold_context_kernel, dim3((unsigned)ceil_div64(K, 64), (unsigned)count), dim3(64 * UF_GROUPS), 0, (hipStream_t)stream, a);
     return vited_check_launch();
 }

@@ -41,6 +41,8 @@ enum { ROW_MODE_FWD = 0, ROW_MODE_BWD = 1 };
 
 struct RowArgs {
     const bf16* A; int64_t lda;
+    int seg_k; int64_t seg_stride;     // the contraction dim may be cut into segments of seg_k columns, segment j starting at A + j * seg_stride
+                                       // (one [M, seg_k] tensor per decoder block: vited_linear_layernorm_bwd_segmented); seg_k = K: one tensor
     const bf16* W; int64_t ldw;
     int64_t M; int K;
     // forward
@@ -122,8 +124,10 @@ gemm_row_kernel(const RowArgs a) {
     auto issue = [&](int stage_idx) {
         char* dst = smem + (stage_idx & (RW_STAGES - 1)) * R::STAGE_BYTES;
         const int k0 = stage_idx * 32;
-        glds16_asm(pa + k0, dst + wave * 1024);      // (the nt policy on this once-read stream costs 0.95 ms per step: measured, not used)
-        if (MT == 9 && wave == 0) glds16_asm(pa8 + k0, dst + 8 * 1024);
+        const int seg = k0 / a.seg_k;                                         // scalar: which [M, seg_k] tensor this K-step reads
+        const int64_t ka = (int64_t)seg * a.seg_stride + (k0 - seg * a.seg_k);
+        glds16_asm(pa + ka, dst + wave * 1024);      // (the nt policy on this once-read stream costs 0.95 ms per step: measured, not used)
+        if (MT == 9 && wave == 0) glds16_asm(pa8 + ka, dst + 8 * 1024);
 #pragma unroll
         for (int i = 0; i < 3; ++i) glds16_asm(pb + i * pstep + k0, dst + R::A_BYTES + (wave * 3 + i) * 1024);
     };
@@ -400,7 +404,7 @@ extern "C" int vited_linear_residual_layernorm_fwd(const void* a, int64_t lda, c
     if (!al16(a) || !al16(w) || !al16(residual) || !al16(y) || !al16(bias) || !al16(gamma) || !al16(beta) || ((uintptr_t)h & 7))
         return VITED_ERR_BAD_ARG;
     RowArgs r = {};
-    r.A = (const bf16*)a; r.lda = lda; r.W = (const bf16*)w; r.ldw = ldw; r.M = M; r.K = (int)K;
+    r.A = (const bf16*)a; r.lda = lda; r.seg_k = (int)K; r.seg_stride = 0; r.W = (const bf16*)w; r.ldw = ldw; r.M = M; r.K = (int)K;
     r.bias = bias; r.residual = residual; r.ldr = ldr; r.y = y; r.ldy = ldy;
     r.gamma = gamma; r.beta = beta; r.eps = eps; r.h = (bf16*)h; r.ldh = ldh; r.mean = mean; r.rstd = rstd;
     return row_launch<ROW_MODE_FWD>(r, (hipStream_t)stream);
@@ -415,24 +419,47 @@ extern "C" int64_t vited_linear_layernorm_bwd_workspace_bytes(int64_t M, int64_t
     return N == ROW_N && M >= 1 ? row_tiles(M) * 2 * ROW_N * (int64_t)sizeof(float) : 0;
 }
 
-extern "C" int vited_linear_layernorm_bwd(const void* dy, int64_t lddy, const void* wt, int64_t ldwt, const float* x, int64_t ldx,
-                                          const float* gamma, const float* mean, const float* rstd, const float* dx_in,
-                                          int64_t dx_in_ld, float* dx_out, int64_t dx_out_ld, void* dx_lp, int64_t dx_lp_ld,
-                                          float* dgamma, float* dbeta, int accumulate, int64_t M, int64_t N, int64_t K,
-                                          float* workspace, int64_t workspace_bytes, void* stream) {
+static int linear_layernorm_bwd_impl(const void* dy, int64_t lddy, int64_t seg_k, int64_t seg_stride, const void* wt, int64_t ldwt,
+                                    const float* x, int64_t ldx, const float* gamma, const float* mean, const float* rstd,
+                                    const float* dx_in, int64_t dx_in_ld, float* dx_out, int64_t dx_out_ld, void* dx_lp, int64_t dx_lp_ld,
+                                    float* dgamma, float* dbeta, int accumulate, int64_t M, int64_t N, int64_t K, float* workspace,
+                                    int64_t workspace_bytes, void* stream) {
     if (!dy || !wt || !x || !gamma || !mean || !rstd || !dx_out || M <= 0 || N <= 0 || K <= 0) return VITED_ERR_BAD_ARG;
     if ((dgamma == nullptr) != (dbeta == nullptr)) return VITED_ERR_BAD_ARG;
-    if (lddy < K || ldwt < K || ldx < N || dx_out_ld < N || (dx_in && dx_in_ld < N) || (dx_lp && dx_lp_ld < N)) return VITED_ERR_BAD_ARG;
-    if (!row_shape_ok(M, N, K)) return VITED_ERR_UNSUPPORTED;
+    if (seg_k <= 0 || K % seg_k || lddy < seg_k || ldwt < K || ldx < N || dx_out_ld < N || (dx_in && dx_in_ld < N) || (dx_lp && dx_lp_ld < N))
+        return VITED_ERR_BAD_ARG;
+    if (!row_shape_ok(M, N, K) || seg_k % 32 || (seg_stride & 7)) return VITED_ERR_UNSUPPORTED;
     if ((lddy & 7) || (ldwt & 7) || (ldx & 3) || (dx_out_ld & 3) || (dx_in && (dx_in_ld & 3)) || (dx_lp && (dx_lp_ld & 3))) return VITED_ERR_UNSUPPORTED;
     if (!al16(dy) || !al16(wt) || !al16(x) || !al16(gamma) || !al16(dx_in) || !al16(dx_out) || ((uintptr_t)dx_lp & 7)) return VITED_ERR_BAD_ARG;
     if (!workspace || workspace_bytes < vited_linear_layernorm_bwd_workspace_bytes(M, N)) return VITED_ERR_WORKSPACE;
     RowArgs r = {};
-    r.A = (const bf16*)dy; r.lda = lddy; r.W = (const bf16*)wt; r.ldw = ldwt; r.M = M; r.K = (int)K;
+    r.A = (const bf16*)dy; r.lda = lddy; r.seg_k = (int)seg_k; r.seg_stride = seg_stride; r.W = (const bf16*)wt; r.ldw = ldwt; r.M = M; r.K = (int)K;
     r.gamma = gamma; r.x = x; r.ldx = ldx; r.mean_in = mean; r.rstd_in = rstd;
     r.dx_in = dx_in; r.ldxi = dx_in_ld; r.dx = dx_out; r.lddx = dx_out_ld; r.dx_lp = (bf16*)dx_lp; r.ldlp = dx_lp_ld;
     r.partial = workspace;
     const int rc = row_launch<ROW_MODE_BWD>(r, (hipStream_t)stream);
     if (rc != VITED_OK || !dgamma) return rc;     // dgamma == null: the caller keeps the partials and finishes several LayerNorms at once
     return ln_bwd_finish(workspace, (int)row_tiles(M), ROW_N, dgamma, dbeta, accumulate, (hipStream_t)stream);
+}
+
+extern "C" int vited_linear_layernorm_bwd(const void* dy, int64_t lddy, const void* wt, int64_t ldwt, const float* x, int64_t ldx,
+                                          const float* gamma, const float* mean, const float* rstd, const float* dx_in,
+                                          int64_t dx_in_ld, float* dx_out, int64_t dx_out_ld, void* dx_lp, int64_t dx_lp_ld,
+                                          float* dgamma, float* dbeta, int accumulate, int64_t M, int64_t N, int64_t K,
+                                          float* workspace, int64_t workspace_bytes, void* stream) {
+    return linear_layernorm_bwd_impl(dy, lddy, K, 0, wt, ldwt, x, ldx, gamma, mean, rstd, dx_in, dx_in_ld, dx_out, dx_out_ld, dx_lp, dx_lp_ld,
+                                     dgamma, dbeta, accumulate, M, N, K, workspace, workspace_bytes, stream);
+}
+
+// dy = `segments` tensors [M, seg_k] (row stride lddy) laid out seg_stride ELEMENTS apart: column block j of the contraction
+// comes from tensor j (the d(kv) of decoder block j, each contiguous for its own attention backward).  wt is [N, segments * seg_k].
+extern "C" int vited_linear_layernorm_bwd_segmented(const void* dy, int64_t lddy, int64_t seg_k, int64_t seg_stride, int64_t segments,
+                                                    const void* wt, int64_t ldwt, const float* x, int64_t ldx, const float* gamma,
+                                                    const float* mean, const float* rstd, const float* dx_in, int64_t dx_in_ld,
+                                                    float* dx_out, int64_t dx_out_ld, void* dx_lp, int64_t dx_lp_ld, float* dgamma,
+                                                    float* dbeta, int accumulate, int64_t M, int64_t N, float* workspace,
+                                                    int64_t workspace_bytes, void* stream) {
+    if (segments <= 0) return VITED_ERR_BAD_ARG;
+    return linear_layernorm_bwd_impl(dy, lddy, seg_k, seg_stride, wt, ldwt, x, ldx, gamma, mean, rstd, dx_in, dx_in_ld, dx_out, dx_out_ld, dx_lp,
+                                     dx_lp_ld, dgamma, dbeta, accumulate, M, N, segments * seg_k, workspace, workspace_bytes, stream);
 }

@@ -704,7 +704,7 @@ def _dec_block_bwd(rt, dx, dx_lp, ctxf, dctx, P, entry, batch, n, cls_only, tap_
 def _context_kv_folded(rt, ctxf, blocks):
     """Keys / values of EVERY decoder block from one LayerNorm and one GEMM (csrc/context_fold.hip): xhat = LayerNorm(features; 1, 0),
     kv_all = xhat W'^T + b' with W'_l = W_l o gamma_l, b'_l = b_l + W_l beta_l stacked over the blocks.
-    Returns (kv_all [Mc, L 2D], (xhat, mean, rstd), folded buffers)."""
+    Returns (kv_all [L, Mc, 2D], (xhat, mean, rstd), folded buffers)."""
     dev = ctxf.device
     if rt._unit_ln is None or rt._unit_ln[0].device != dev:
         rt._unit_ln = (torch.ones(rt.dim, dtype=torch.float32, device=dev), torch.zeros(rt.dim, dtype=torch.float32, device=dev))
@@ -717,7 +717,12 @@ def _context_kv_folded(rt, ctxf, blocks):
     rt._fold_bufs = bufs = ops.fold_context_weights([w.detach() for w in ws], [b.detach() if b is not None else None for b in bs],
                                                     [g.detach() for g in gs], [b.detach() for b in bes], out=bufs)
     xhat, mean, rstd = ops.layernorm_fwd(ctxf, rt._unit_ln[0], rt._unit_ln[1], LN_EPS, rt.act_dtype)
-    kv_all = ops.gemm(xhat, bufs[0], bias=bufs[2])
+    # one [Mc, 2D] tensor per block (each block's attention then reads dense rows; ONE [Mc, L 2D] product would also push the stacked
+    # weights - 4.7 MB at 8 blocks - out of an XCD's L2: measured 690 us for the single GEMM against 8 x 55 us)
+    n2 = 2 * rt.dim
+    kv_all = torch.empty((len(blocks), ctxf.shape[0], n2), dtype=rt.act_dtype, device=dev)
+    for l in range(len(blocks)):
+        ops.gemm(xhat, bufs[0][l * n2:(l + 1) * n2], bias=bufs[2][l * n2:(l + 1) * n2], out=kv_all[l])
     return kv_all, (xhat, mean, rstd), bufs
 
 
@@ -728,12 +733,22 @@ def _context_kv_folded_bwd(rt, dkv_all, ctxf, saved, bufs, blocks):
     Returns (d features fp32, [(dgx, dbx, dwkv, dbkv) per block] - None entries when accumulated straight into .grad)."""
     xhat, mean, rstd = saved
     ones = rt._unit_ln[0]
-    if _row_kernel_ok(rt, dkv_all.shape[0], bufs[1].shape[0], dkv_all.shape[1], dkv_all.dtype, dkv_all, ctxf):
-        dctx, _, _, _ = ops.linear_layernorm_bwd(dkv_all, bufs[1], ctxf, ones, mean, rstd)
+    nblk, mc, n2 = dkv_all.shape
+    if _row_kernel_ok(rt, mc, bufs[1].shape[0], nblk * n2, dkv_all.dtype, ctxf):
+        dctx, _, _, _ = ops.linear_layernorm_bwd(dkv_all, bufs[1], ctxf, ones, mean, rstd)      # contraction over all blocks' d(kv)
     else:
-        dh = ops.gemm(dkv_all, bufs[1])
+        dh = torch.zeros((mc, rt.dim), dtype=torch.float32, device=ctxf.device)
+        for l in range(nblk):
+            dh = ops.gemm(dkv_all[l], bufs[1][:, l * n2:(l + 1) * n2], epilogue=EPI_RESIDUAL, residual=dh)
         dctx, _, _, _ = ops.layernorm_bwd(dh, ctxf, ones, mean, rstd)
-    dwf, dbf = ops.linear_bwd_weight(dkv_all, xhat)
+    dwf = torch.empty((nblk * n2, rt.dim), dtype=torch.float32, device=ctxf.device)
+    dbf = torch.empty(nblk * n2, dtype=torch.float32, device=ctxf.device)
+    items = [(dkv_all[l], xhat, dwf[l * n2:(l + 1) * n2], dbf[l * n2:(l + 1) * n2]) for l in range(nblk)]
+    for i in range(0, nblk, ops.MAX_BATCHED_WEIGHT_GRADS):
+        part = items[i: i + ops.MAX_BATCHED_WEIGHT_GRADS]
+        if not (len(part) > 1 and ops.linear_bwd_weight_batched(part, False)):
+            for dy_, x_, dw_, db_ in part:
+                _overwrite_weight_grad(dy_, x_, dw_, db_)
     ws, bs, gs, bes = [P[12] for P in blocks], [P[13] for P in blocks], [P[8] for P in blocks], [P[9] for P in blocks]
     targets = [(_gtarget(rt, w), _gtarget(rt, b) if b is not None else None, _gtarget(rt, g), _gtarget(rt, be)) for w, b, g, be in zip(ws, bs, gs, bes)]
     direct = all(t[0] is not None and t[2] is not None and t[3] is not None and (b is None or t[1] is not None) for t, b in zip(targets, bs))
@@ -764,11 +779,10 @@ class DecoderFn(torch.autograd.Function):
         kv_all = kv_saved = fold_bufs = None
         if fold:
             kv_all, kv_saved, fold_bufs = _context_kv_folded(rt, ctxf, blocks)
-            kv_all3 = kv_all.view(batch, rt.n1, rt.c_depth * 2 * d)
         for i, P in enumerate(blocks):
             nxt = (blocks[i + 1][0], blocks[i + 1][1]) if i + 1 < rt.c_depth else None     # the next block's norm1
             x, entry, ln1 = _dec_block_fwd(rt, x, ctxf, P, batch, n, grad, cls_tail and i == rt.c_depth - 1, index=i, ln1=ln1, next_ln=nxt,
-                                           kv3=kv_all3[:, :, i * 2 * d:(i + 1) * 2 * d] if fold else None)
+                                           kv3=kv_all[i].view(batch, rt.n1, 2 * d) if fold else None)
             if grad:
                 tape.append(entry)
             if rt.tap is not None:
@@ -818,7 +832,7 @@ class DecoderFn(torch.autograd.Function):
         dkv_all3 = None
         if ctx.fold is not None:
             dkv_all = torch.empty_like(ctx.fold[0])
-            dkv_all3 = dkv_all.view(batch, rt.n1, rt.c_depth * 2 * d)
+            dkv_all3 = dkv_all
         for i in reversed(range(rt.c_depth)):
             P = params[ns + i * nb: ns + (i + 1) * nb]
             entry = ctx.tape[i]
@@ -826,7 +840,7 @@ class DecoderFn(torch.autograd.Function):
             with _DwBatch(rt):
                 dx, dx_lp, dctx, blk = _dec_block_bwd(rt, dx, dx_lp, ctx.ctxf, dctx, P, entry, batch, n,
                                                       ctx.cls_tail and i == rt.c_depth - 1, i,
-                                                      dkv3=dkv_all3[:, :, i * 2 * d:(i + 1) * 2 * d] if dkv_all3 is not None else None)
+                                                      dkv3=dkv_all3[i].view(batch, rt.n1, 2 * d) if dkv_all3 is not None else None)
             if rt.tap is not None:
                 rt.tap[f'dec.dx.{i}'] = dx.clone()      # gradient w.r.t. the INPUT of decoder block i
                 if dctx is not None:

@@ -397,8 +397,16 @@ def linear_layernorm_bwd(dy, wt, x, gamma, mean, rstd, dx_in=None, dx_out=None, 
     ``layernorm_bwd_finish(defer)`` later finishes many LayerNorms with one launch."""
     _need_gpu(dy, wt, x, gamma, mean, rstd, dx_in, dx_out)
     assert dy.dtype == wt.dtype == torch.bfloat16 and x.dtype == torch.float32
-    lddy, ldwt, ldx = _rows2d(dy), _rows2d(wt), _rows2d(x)
-    m, k = dy.shape
+    segments = 1
+    if dy.dim() == 3:
+        # [L, M, seg_k]: the contraction dim arrives as L tensors (one per decoder block), wt is [N, L * seg_k]
+        assert dy.stride(2) == 1 and dy.stride(0) % 8 == 0
+        segments, m, seg_k = dy.shape
+        lddy, seg_stride, k = dy.stride(1), dy.stride(0), segments * seg_k
+    else:
+        lddy = _rows2d(dy)
+        m, k = dy.shape
+    ldwt, ldx = _rows2d(wt), _rows2d(x)
     n = wt.shape[0]
     assert wt.shape[1] == k and x.shape == (m, n)
     lib = _lib.load()
@@ -417,11 +425,14 @@ def linear_layernorm_bwd(dy, wt, x, gamma, mean, rstd, dx_in=None, dx_out=None, 
         defer.append((ws, rows, dgamma, dbeta, accumulate))
     else:
         ws = workspace(lib.vited_linear_layernorm_bwd_workspace_bytes(m, n), x.device)
-    _lib.check(lib.vited_linear_layernorm_bwd(
-        _ptr(dy), lddy, _ptr(wt), ldwt, _ptr(x), ldx, _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dx_in),
-        _rows2d(dx_in) if dx_in is not None else 0, _ptr(dx_out), _rows2d(dx_out), _ptr(dx_lp), n,
-        0 if defer is not None else _ptr(dgamma), 0 if defer is not None else _ptr(dbeta),
-        int(accumulate), m, n, k, _ptr(ws), ws.numel() * 4, _stream()), 'vited_linear_layernorm_bwd')
+    tail = (_ptr(x), ldx, _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dx_in), _rows2d(dx_in) if dx_in is not None else 0, _ptr(dx_out),
+            _rows2d(dx_out), _ptr(dx_lp), n, 0 if defer is not None else _ptr(dgamma), 0 if defer is not None else _ptr(dbeta), int(accumulate))
+    if segments > 1:
+        _lib.check(lib.vited_linear_layernorm_bwd_segmented(_ptr(dy), lddy, seg_k, seg_stride, segments, _ptr(wt), ldwt, *tail, m, n, _ptr(ws),
+                                                            ws.numel() * 4, _stream()), 'vited_linear_layernorm_bwd_segmented')
+    else:
+        _lib.check(lib.vited_linear_layernorm_bwd(_ptr(dy), lddy, _ptr(wt), ldwt, *tail, m, n, k, _ptr(ws), ws.numel() * 4, _stream()),
+                   'vited_linear_layernorm_bwd')
     return dx_out, dx_lp, dgamma, dbeta
 
 
