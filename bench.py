@@ -257,16 +257,20 @@ class LaunchTimer:
                    lambda a, k: attn_bytes(a, k, True))
         self._wrap('layernorm_fwd', lambda a, k: 0.0, lambda a, k, gp, ap: 'layernorm_fwd_kernel', ln_fwd_bytes)
         self._wrap('layernorm_bwd', lambda a, k: 0.0, lambda a, k, gp, ap: 'layernorm_bwd_kernel', ln_bwd_bytes)
+        def row_mk(t):                 # [M, K], or [L, M, seg_k]: the contraction dim as L tensors (all decoder blocks' d(kv))
+            return (t.shape[1], t.shape[0] * t.shape[2]) if t.dim() == 3 else (t.shape[0], t.shape[1])
+
         def row_flops(a, k):           # a . W^T with W [384, K]
-            return 2.0 * a[0].shape[0] * a[0].shape[1] * a[1].shape[0]
+            m, kk = row_mk(a[0])
+            return 2.0 * m * kk * a[1].shape[0]
 
         def row_fwd_bytes(a, k):       # a, W in; residual in, y out (fp32); h out (bf16) when the LayerNorm is fused
-            m, kk = a[0].shape
+            m, kk = row_mk(a[0])
             n = a[1].shape[0]
             return float(m * kk * 2 + n * kk * 2 + m * n * (4 + 4 + (2 if len(a) > 4 and a[4] is not None or k.get('gamma') is not None else 0)))
 
         def row_bwd_bytes(a, k):       # dy, Wt in; x, dx_in in; dx (+ bf16 copy) out
-            m, kk = a[0].shape
+            m, kk = row_mk(a[0])
             n = a[1].shape[0]
             return float(m * kk * 2 + n * kk * 2 + m * n * (4 + (4 if k.get('dx_in') is not None else 0) + 4 + (2 if k.get('want_lp') else 0)))
 

@@ -228,7 +228,7 @@ int vited_fold_context_weights(int count, const float* const* w, const float* co
                                const float* const* beta, int64_t N, int64_t K, void* w_out, void* wt_out, float* bias_out,
                                void* stream);
 int vited_unfold_context_grads(int count, const float* dwf, const float* dbf, const float* const* w, const float* const* gamma,
-                               float* const* dw, float* const* dbias, float* const* dgamma, float* const* dbeta, int64_t N,
+                               const float* const* beta, float* const* dw, float* const* dbias, float* const* dgamma, float* const* dbeta, int64_t N,
                                int64_t K, int accumulate, void* stream);
 
 /* ---- fused MLP branch of a block: y = x + fc2(gelu(fc1(LayerNorm(x)))) (vision_transformer.py:126,271; timm Mlp :115,:259) ---- */

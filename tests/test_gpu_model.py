@@ -699,3 +699,36 @@ def test_streamed_similarity_is_block_resident_resumable_and_matches_the_oracle(
     per_image_cache = 65 * 384 * (4 + 2)           # image-2 tokens fp32 + cached queries bf16, what an all-image cache would hold
     assert p96 - p24 < 8 * per_image_cache + 96 * 96 * 2 + 4 * 96 * 97 // 2 + (1 << 20), (p24, p96)
     assert 72 * per_image_cache > 8 * per_image_cache + (2 << 20)    # i.e. the bound is far below what 72 more resident images cost
+
+
+def test_folded_context_kv_matches_the_per_block_form(vited, gpu):
+    """norm_context + kv of all decoder blocks through folded weights (functions._context_kv_folded, csrc/context_fold.hip) against
+    the per-block LayerNorm + Linear it replaces, same bf16 kernels otherwise, on closed-form weights (gamma != 1, beta != 0: at the
+    reference's init the fold is the identity).  Logits, d(features) and - per tensor - the gradients that travel through the fold:
+    norm_context.{weight, bias}, cross_attn.kv.{weight, bias} (kv.weight also receives the bias path's  db' beta^T  term)."""
+    s = vo.ViTEDShape(depth=1, c_depth=3)
+    x = vo.closed_form_pairs(6, s).to(gpu)
+    y = _targets(6, s, gpu)
+    runs = {}
+    for fold in (True, False):
+        model = vo.fill_closed_form_(_hip_model(vited, s, gpu, torch.bfloat16))
+        rt = model.runtime()
+        rt.fold_context = fold
+        feats = model(x[:, 0], forward_first_part=True)
+        leaf = feats.detach().requires_grad_(True)
+        logits = model(leaf, x[:, 1])
+        torch.nn.functional.binary_cross_entropy_with_logits(logits, y).backward()
+        runs[fold] = (logits.detach(), leaf.grad.clone(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None})
+    (l1, d1, g1), (l0, d0, g0) = runs[True], runs[False]
+    torch.testing.assert_close(l1, l0, rtol=2e-2, atol=2e-2)
+    rel = lambda a, b: float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+    assert rel(d1, d0) < 3e-2, f'd(features): {rel(d1, d0):.3e}'
+    worst = {}
+    for n in g0:
+        if 'norm_context' in n or 'cross_attn.kv' in n:
+            worst[n] = rel(g1[n], g0[n])
+            assert worst[n] < 3e-2, f'{n}: folded vs per-block gradient differs by {worst[n]:.3e}'
+    assert len(worst) == 12
+    # sanity of the case itself: the bias path matters here (beta is not ~0), so a fold that forgot it would be caught
+    blk = dict(model.named_parameters())
+    assert float(blk['cross_blocks.0.norm_context.bias'].abs().mean()) > 1e-2

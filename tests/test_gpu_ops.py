@@ -605,7 +605,7 @@ def test_context_fold_unfold_and_segmented_backward(vited, gpu):
     dbf = torch.cat([dkv[l].double().sum(0) for l in range(L)]).float()
     for accumulate in (False, True):
         tgt = [[torch.full_like(t, 0.5 if accumulate else float('nan')) for t in (ws[l], cs[l], gs[l], bs[l])] for l in range(L)]
-        ops.unfold_context_grads(dwf, dbf, ws, gs, [t[0] for t in tgt], [t[1] for t in tgt], [t[2] for t in tgt], [t[3] for t in tgt], accumulate)
+        ops.unfold_context_grads(dwf, dbf, ws, gs, bs, [t[0] for t in tgt], [t[1] for t in tgt], [t[2] for t in tgt], [t[3] for t in tgt], accumulate)
         base = 0.5 if accumulate else 0.0
         for l in range(L):
             for got, ref in zip(tgt[l], prm[l]):

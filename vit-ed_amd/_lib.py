@@ -57,7 +57,7 @@ SIGNATURES = {
     'vited_linear_layernorm_bwd': (_i, [_p, _i64, _p, _i64, _p, _i64, _p, _p, _p, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i, _i64, _i64, _i64,
                                         _p, _i64, _p]),
     'vited_fold_context_weights': (_i, [_i, _p, _p, _p, _p, _i64, _i64, _p, _p, _p, _p]),
-    'vited_unfold_context_grads': (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i, _p]),
+    'vited_unfold_context_grads': (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i, _p]),
     'vited_mlp_fwd': (_i, [_p, _i64, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _p, _p, _p, _p, _i64, _i64, _i64, _f, _p]),
     'vited_block_workspace_bytes': (_i64, [_i64, _i64, _i64, _i64, _i]),
     'vited_block_fwd': (_i, [_p, _p, _i64, _i64, _i64, _i, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _i64, _p]),

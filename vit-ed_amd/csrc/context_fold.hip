@@ -7,7 +7,8 @@
 // and the c_depth LayerNorm launches + c_depth kv GEMMs become ONE LayerNorm (gamma = 1, beta = 0) and ONE GEMM against the
 // folded weights of all blocks stacked ([c_depth * 2 D, D]); in backward the c_depth input-gradient GEMMs + LayerNorm backwards
 // become one row-complete kernel with K = c_depth * 2 D, and the gradients of the folded weights unfold as
-//     dW_l = dW'_l o gamma_l,   dgamma_l[k] = sum_n dW'_l[n, k] W_l[n, k],   dbeta_l[k] = sum_n db'_l[n] W_l[n, k],   db_l = db'_l.
+//     dW_l[n, k] = dW'_l[n, k] gamma_l[k] + db'_l[n] beta_l[k]   (W_l enters W'_l AND b'_l),
+//     dgamma_l[k] = sum_n dW'_l[n, k] W_l[n, k],   dbeta_l[k] = sum_n db'_l[n] W_l[n, k],   db_l = db'_l.
 // The two kernels here touch c_depth * 2 D * D elements (2.4 M at config A): microseconds.
 #include "common.h"
 
@@ -65,6 +66,7 @@ extern "C" int vited_fold_context_weights(int count, const float* const* w, cons
 struct UnfoldArgs {
     const float* w[CF_MAX_BLOCKS];
     const float* gamma[CF_MAX_BLOCKS];
+    const float* beta[CF_MAX_BLOCKS];
     float* dw[CF_MAX_BLOCKS];            // [N, K]
     float* dbias[CF_MAX_BLOCKS];         // [N] or null
     float* dgamma[CF_MAX_BLOCKS];        // [K]
@@ -86,16 +88,17 @@ __global__ void __launch_bounds__(64 * UF_GROUPS) unfold_context_kernel(const Un
     const float* __restrict__ dwf = a.dwf + (int64_t)l * a.N * a.K;
     const float* __restrict__ dbf = a.dbf + (int64_t)l * a.N;
     float* __restrict__ dw = a.dw[l];
-    const float g = ok ? a.gamma[l][k] : 0.f;
+    const float g = ok ? a.gamma[l][k] : 0.f, be = ok ? a.beta[l][k] : 0.f;
     float sg = 0.f, sb = 0.f;
 #pragma unroll 4
     for (int n = ng; n < a.N; n += UF_GROUPS) {
         if (ok) {
             const int64_t o = (int64_t)n * a.K + k;
-            const float d = dwf[o], wv = w[o];
+            const float d = dwf[o], wv = w[o], dbn = dbf[n];
             sg = fmaf(d, wv, sg);
-            sb = fmaf(dbf[n], wv, sb);
-            dw[o] = a.accumulate ? dw[o] + d * g : d * g;
+            sb = fmaf(dbn, wv, sb);
+            const float v = fmaf(d, g, dbn * be);
+            dw[o] = a.accumulate ? dw[o] + v : v;
         }
     }
     red[0][ng][kx] = sg;
@@ -117,14 +120,14 @@ __global__ void __launch_bounds__(64 * UF_GROUPS) unfold_context_kernel(const Un
 }
 
 extern "C" int vited_unfold_context_grads(int count, const float* dwf, const float* dbf, const float* const* w, const float* const* gamma,
-                                          float* const* dw, float* const* dbias, float* const* dgamma, float* const* dbeta, int64_t N,
+                                          const float* const* beta, float* const* dw, float* const* dbias, float* const* dgamma, float* const* dbeta, int64_t N,
                                           int64_t K, int accumulate, void* stream) {
-    if (count < 1 || count > CF_MAX_BLOCKS || !dwf || !dbf || !w || !gamma || !dw || !dbias || !dgamma || !dbeta || N <= 0 || K <= 0)
+    if (count < 1 || count > CF_MAX_BLOCKS || !dwf || !dbf || !w || !gamma || !beta || !dw || !dbias || !dgamma || !dbeta || N <= 0 || K <= 0)
         return VITED_ERR_BAD_ARG;
     UnfoldArgs a = {};
     for (int i = 0; i < count; ++i) {
-        if (!w[i] || !gamma[i] || !dw[i] || !dgamma[i] || !dbeta[i]) return VITED_ERR_BAD_ARG;
-        a.w[i] = w[i]; a.gamma[i] = gamma[i]; a.dw[i] = dw[i]; a.dbias[i] = dbias[i]; a.dgamma[i] = dgamma[i]; a.dbeta[i] = dbeta[i];
+        if (!w[i] || !gamma[i] || !beta[i] || !dw[i] || !dgamma[i] || !dbeta[i]) return VITED_ERR_BAD_ARG;
+        a.w[i] = w[i]; a.gamma[i] = gamma[i]; a.beta[i] = beta[i]; a.dw[i] = dw[i]; a.dbias[i] = dbias[i]; a.dgamma[i] = dgamma[i]; a.dbeta[i] = dbeta[i];
     }
     a.dwf = dwf; a.dbf = dbf; a.count = count; a.N = (int)N; a.K = (int)K; a.accumulate = accumulate;
     hipLaunchKernelGGL(unfold_context_kernel, dim3((unsigned)ceil_div64(K, 64), (unsigned)count), dim3(64 * UF_GROUPS), 0, (hipStream_t)stream, a);

@@ -755,7 +755,7 @@ def _context_kv_folded_bwd(rt, dkv_all, ctxf, saved, bufs, blocks):
     if not direct:
         targets = [(torch.empty_like(w), torch.empty_like(b) if b is not None else None, torch.empty_like(g), torch.empty_like(be))
                    for w, b, g, be in zip(ws, bs, gs, bes)]
-    ops.unfold_context_grads(dwf, dbf, [w.detach() for w in ws], [g.detach() for g in gs], [t[0] for t in targets], [t[1] for t in targets],
+    ops.unfold_context_grads(dwf, dbf, [w.detach() for w in ws], [g.detach() for g in gs], [b.detach() for b in bes], [t[0] for t in targets], [t[1] for t in targets],
                              [t[2] for t in targets], [t[3] for t in targets], accumulate=direct)
     return dctx, [(None, None, None, None) if direct else (t[2], t[3], t[0], t[1]) for t in targets]
 

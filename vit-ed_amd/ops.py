@@ -474,7 +474,7 @@ def fold_context_weights(ws, biases, gammas, betas, out=None):
     return out
 
 
-def unfold_context_grads(dwf, dbf, ws, gammas, dws, dbiases, dgammas, dbetas, accumulate: bool):
+def unfold_context_grads(dwf, dbf, ws, gammas, betas, dws, dbiases, dgammas, dbetas, accumulate: bool):
     """Gradients of the folded weights / bias -> dW_l, db_l, dgamma_l, dbeta_l (``vited_unfold_context_grads``)."""
     import ctypes as C
     n_blk = len(ws)
@@ -483,7 +483,8 @@ def unfold_context_grads(dwf, dbf, ws, gammas, dws, dbiases, dgammas, dbetas, ac
     assert dwf.shape == (n_blk * n, k) and dbf.numel() == n_blk * n
     vp = C.c_void_p * n_blk
     _lib.check(_lib.load().vited_unfold_context_grads(n_blk, _ptr(dwf), _ptr(dbf), vp(*[w.data_ptr() for w in ws]),
-                                                      vp(*[g.data_ptr() for g in gammas]), vp(*[t.data_ptr() for t in dws]),
+                                                      vp(*[g.data_ptr() for g in gammas]), vp(*[b.data_ptr() for b in betas]),
+                                                      vp(*[t.data_ptr() for t in dws]),
                                                       vp(*[_ptr(t) or None for t in dbiases]), vp(*[t.data_ptr() for t in dgammas]),
                                                       vp(*[t.data_ptr() for t in dbetas]), n, k, int(bool(accumulate)), _stream()),
                'vited_unfold_context_grads')
