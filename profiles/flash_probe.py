@@ -17,10 +17,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--batch', type=int, default=72)
     ap.add_argument('--reps', type=int, default=6)
+    ap.add_argument('--tokens', type=int, default=1024, help='1025 = the decoder\'s sequence (cls + 1024 patches): a one-token tail tile')
     ap.add_argument('--no-time', action='store_true')
     a = ap.parse_args()
     dev = torch.device('cuda:0')
-    B, H, N, hd = a.batch, 6, 1024, 64
+    B, H, N, hd = a.batch, 6, a.tokens, 64
     D = H * hd
     g = torch.Generator().manual_seed(0)
     qkv = torch.randn(B, N, 3 * D, generator=g).to(dev).bfloat16()
@@ -43,7 +44,7 @@ def main():
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / a.reps * 1e3
         if not a.no_time:
-            print(f'flash {name} B={B}: {us:.1f} us {f / us / 1e6:.0f} TFLOP/s')
+            print(f'flash {name} B={B} N={N}: {us:.1f} us {f / us / 1e6:.0f} TFLOP/s')
 
 
 if __name__ == '__main__':
