@@ -164,6 +164,7 @@ __device__ __forceinline__ void epilogue_subtile(const EpiParams& p, const EpiPr
             for (int e = 0; e < 8; ++e) pk[e] = (bf16)v[e];
             // the plain-store outputs (qkv / kv / q, do) are read by the very NEXT kernel (attention, the next GEMM): a normal store
             // leaves them where that kernel finds them (step 25.35 -> 25.2 ms against the streaming hint); everything else streams
+            // (u = gelu(z) and dz also feed the next kernel, but at 200 MB each a normal store costs 0.45 ms: measured)
             if constexpr (EPI == VITED_EPI_STORE) *(bf16x8*)((bf16*)p.out + m * p.ldo + n) = pk;
             else EPI_STORE16((bf16x8*)((bf16*)p.out + m * p.ldo + n), pk);
             if constexpr (EPI == VITED_EPI_GELU) {
