@@ -507,3 +507,51 @@ def test_flat_adamw_resume_before_bind_keeps_the_step_count(vited, gpu):
     opt.load_state_dict(ckpt['opt'])
     assert opt.exp_avg.data_ptr() == ptr and opt.num_updates == 5
     torch.testing.assert_close(opt.state[mine[0]]['exp_avg'], ckpt['opt']['state'][0]['exp_avg'])
+
+
+def test_graphs_are_recaptured_when_the_shadow_set_changes(vited, gpu):
+    """The captured graphs bake in WHICH bf16 weight-shadow buffers the forward / backward read and the update kernel refreshes.
+    If a shadow is re-created after capture (here: two cache entries replaced by hand, as a parameter whose storage moved would
+    cause), replaying the old graphs would train on stale weights.  TrainStep compares the shadow set at the start of every
+    accumulation cycle, drops the graphs, runs that cycle eagerly and captures again: training continues bit-identically to the
+    eagerly launched twin."""
+    s = vo.ViTEDShape(depth=1, c_depth=1)
+    torch.manual_seed(9)
+    init = _hip_model(vited, s, gpu, None).state_dict()
+    models, steps = [], []
+    for use_graph in (False, True):
+        m = _hip_model(vited, s, gpu, None)
+        m.load_state_dict(init)
+        opt = vited.optim.FlatAdamW(vited.engine.param_groups_no_decay_1d(m), lr=1e-3, weight_decay=0.05, model=m)
+        steps.append(vited.engine.TrainStep(m, opt, clip_grad=5.0, amp=True, use_graph=use_graph))
+        models.append(m)
+    g = torch.Generator().manual_seed(4)
+
+    def run(n):
+        for _ in range(n):
+            x = torch.randn(8, 2, 3, 64, 64, generator=g).clamp(-1, 1).to(gpu)
+            y = (torch.rand(8, 4, generator=g) > 0.6).float().to(gpu)
+            le, lg = [float(st.step(x, y)) for st in steps]
+            assert le == lg
+
+    run(4)
+    assert steps[1]._g_opt is not None and steps[1].recaptures == 0
+    rt = models[1].runtime(torch.bfloat16)
+    w = models[1].blocks[0].mlp.fc1.weight
+    before = {k: v[2].data_ptr() for k, v in rt._shadow.items() if k[0] == id(w)}
+    assert set(t for _, t in before) == {'n', 't'}
+    for k in before:
+        old = rt._shadow.pop(k)
+        rt._retired.append(old[2])
+    rt.weight(w), rt.weight_t(w)
+    after = {k: v[2].data_ptr() for k, v in rt._shadow.items() if k[0] == id(w)}
+    assert all(after[k] != before[k] for k in before)
+    run(1)
+    assert steps[1].recaptures == 1 and steps[1]._g1 is None, 'the changed shadow set must drop the graphs (this step ran eagerly)'
+    # the update refreshed the NEW buffers: they hold the current weights
+    assert torch.equal(rt._shadow[(id(w), 'n')][2], w.detach().to(torch.bfloat16))
+    assert torch.equal(rt._shadow[(id(w), 't')][2], w.detach().t().contiguous().to(torch.bfloat16))
+    run(3)
+    assert steps[1].recaptures == 1 and steps[1]._g1 is not None, 'graphs are captured again and replayed'
+    for (n, pe), (_, pg) in zip(models[0].named_parameters(), models[1].named_parameters()):
+        assert torch.equal(pe, pg), f'{n}: graph path differs from eager launches after the re-capture'

@@ -164,16 +164,27 @@ gemm_row_kernel(const RowArgs a) {
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             const bool dma_first = wave >= 4;     // waves w and w + 4 share a SIMD: one issues DMA while the other's MFMAs hold the pipe
+#ifndef ROW_DBG_NO_DMA
             if (dma_first && t + RW_STAGES < nsteps) issue(t + RW_STAGES);     // into the slot stage t has just left
+#endif
+#ifndef ROW_DBG_NO_READS
             if (t + 1 < nsteps) read_frags(nxt, smem + ((t + 1) & (RW_STAGES - 1)) * R::STAGE_BYTES);
+#endif
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < 3; ++j)
 #pragma unroll
-                for (int i = 0; i < MT; ++i)   // transposed product: lane holds row (16 i + fr), columns 48 wave + 16 j + 4 fq + (0..3)
+                for (int i = 0; i < MT; ++i) {  // transposed product: lane holds row (16 i + fr), columns 48 wave + 16 j + 4 fq + (0..3)
+#ifdef ROW_DBG_NO_MFMA
+                    asm volatile("" ::"v"(cur.b[j]), "v"(cur.a[i]));
+#else
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur.b[j], cur.a[i], acc[i][j], 0, 0, 0);
+#endif
+                }
             __builtin_amdgcn_sched_barrier(0);
+#ifndef ROW_DBG_NO_DMA
             if (!dma_first && t + RW_STAGES < nsteps) issue(t + RW_STAGES);
+#endif
         };
 #pragma unroll
         for (int pre = 0; pre < RW_STAGES; ++pre)
@@ -196,6 +207,13 @@ gemm_row_kernel(const RowArgs a) {
     };
     if (MT == 9 && wave == 0) mainloop(std::integral_constant<int, 5>{});
     else mainloop(std::integral_constant<int, 4>{});
+#ifdef ROW_DBG_NO_EPI                        // timing experiment: main loop only
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) asm volatile("" ::"v"(acc[i][j]));
+    return;
+#endif
 #ifdef ROW_DBG_NO_EPI                        // timing experiment: main loop only
 #pragma unroll
     for (int i = 0; i < MT; ++i)

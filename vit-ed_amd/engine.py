@@ -412,6 +412,14 @@ class TrainStep:
         last update."""
         last = (self._micro + 1) % self.accum == 0
         self._micro += 1
+        if (self._g1 is not None and self.hip_opt and (self._micro - 1) % self.accum == 0
+                and self.optimizer.shadow_signature() != self._opt_signature):
+            # a bf16 weight shadow was re-created (or added) after capture: the captured forward / backward graphs read the old
+            # buffers and the captured update refreshes the old set.  Drop every graph; this cycle runs eagerly, the next re-captures.
+            torch.cuda.synchronize()
+            self._g1 = self._g2 = self._g_opt = None
+            self._eager_steps = 2 * self.accum - self.accum
+            self.recaptures += 1
         if self.use_graph and self._g1 is None and self._eager_steps >= 2 * self.accum and (self._micro - 1) % self.accum == 0:
             self._capture(x, y)     # at the start of an accumulation cycle, after two eager updates: the flat buffer is zero
         if self._g1 is None:
@@ -433,10 +441,6 @@ class TrainStep:
                 self.flat.start_all_reduce(0, self.flat.flat.numel(), group=self.group)
             self.flat.finish_all_reduce()
             self._sync_lr()
-            if self.hip_opt and self.optimizer.shadow_signature() != self._opt_signature:
-                # a weight shadow was created (or moved) after capture: the captured descriptor table does not refresh it
-                self._capture_update()
-                self.recaptures += 1
             self._g_opt.replay()
             self.last_norm = self._static_norm
             self._after_update()
