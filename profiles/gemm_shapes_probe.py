@@ -15,8 +15,8 @@ import vited_amd as v  # noqa: E402
 
 ops, L = v.ops, v._lib
 
-NT = [(1152, 384, L.EPI_STORE, 'qkv'), (384, 384, L.EPI_RESIDUAL, 'proj+res'), (1536, 384, L.EPI_GELU, 'fc1+gelu'),
-      (384, 1536, L.EPI_RESIDUAL, 'fc2+res'), (1536, 384, L.EPI_MUL_GELU_GRAD, 'dz=dy.W2*gelu\''), (384, 1536, L.EPI_STORE, 'dh=dz.W1'),
+NT = [(1152, 384, L.EPI_STORE, 'qkv'), (384, 384, L.EPI_RESIDUAL, 'proj+res'), (1536, 384, L.EPI_GELU_GRAD, "fc1+gelu'+gelu"),
+      (384, 1536, L.EPI_RESIDUAL, 'fc2+res'), (1536, 384, L.EPI_MUL, "dz=dy.W2*gelu'"), (384, 1536, L.EPI_STORE, 'dh=dz.W1'),
       (384, 1152, L.EPI_STORE, 'dh=dqkv.Wqkv'), (384, 384, L.EPI_STORE, 'do=dx.Wp'), (768, 384, L.EPI_STORE, 'kv')]
 TN = [(1152, 384, 'dWqkv'), (384, 384, 'dWproj'), (1536, 384, 'dWfc1'), (384, 1536, 'dWfc2'), (768, 384, 'dWkv')]
 
@@ -54,7 +54,7 @@ def main():
         kw = dict(epilogue=epi, bias=bias)
         if epi == L.EPI_RESIDUAL:
             kw['residual'] = rnd(M, n)
-        if epi == L.EPI_MUL_GELU_GRAD:
+        if epi in (L.EPI_MUL_GELU_GRAD, L.EPI_MUL):
             kw['aux'], kw['bias'] = rnd(M, n).bfloat16(), None
         timed(lambda: ops.gemm(x, w, **kw), f'{name} N={n} K={k}', 2.0 * M * n * k)
     print(f'TN (M = {M})')

@@ -180,11 +180,15 @@ def test_gemm_all_epilogues(vited, gpu, dtype, M, N, K):
 
 
 @pytest.mark.parametrize('M,N,K', [(8192, 1152, 384), (8321, 768, 384), (16640, 1536, 384), (8257, 384, 1536), (8320, 384, 384),
-                                   (9000, 384, 1152)])
+                                   (9000, 384, 1152),
+                                   # the 256 x 128 tile under the GELU' and multiply epilogues (fc1 / dz at M >= 8,192, N >= 768,
+                                   # K <= 512): a ragged last row tile, the narrowest N and the shortest / a non-384 contraction
+                                   (16555, 1536, 384), (16391, 768, 128), (16400, 1024, 512)])
 def test_gemm_bench_scale_tiles(vited, gpu, M, N, K):
-    """The tile variants only large launches select (256-row / 8-wave tiles for M >= 8192, BK = 64 at N = 384, the
-    XCD-aware tile order over thousands of tiles) with ragged last row tiles (M % 128 != 0): every epilogue, every output
-    element, against fp64 on the same bf16-rounded operands; plus the weight-gradient kernel's full split-K geometry."""
+    """The tile variants only large launches select (256-row / 8-wave tiles for M >= 8192 - plain store, fc1 + GELU' and the
+    dz multiply -, BK = 64 at N = 384, the XCD-aware tile order over thousands of tiles) with ragged last row tiles
+    (M % 128 != 0): every epilogue, every output element, against fp64 on the same bf16-rounded operands; plus the
+    weight-gradient kernel's full split-K geometry."""
     ops, L = vited.ops, vited._lib
     a = _rand((M, K), gpu, 21, dtype=torch.bfloat16)
     w = _rand((N, K), gpu, 22, 1 / math.sqrt(K), dtype=torch.bfloat16)
@@ -204,6 +208,14 @@ def test_gemm_bench_scale_tiles(vited, gpu, M, N, K):
     F.gelu(xg).sum().backward()
     dz = ops.gemm(a, w, epilogue=L.EPI_MUL_GELU_GRAD, aux=aux)
     torch.testing.assert_close(dz.double(), _gemm_ref(a, w, None) * xg.grad, **BF16_OUT)
+    # what fc1 saves in training (gelu'(z), gelu(z)) and the GELU backward as one multiply (dz = (dy . W2^T) * gelu'(z))
+    gd, u2 = ops.gemm(a, w, epilogue=L.EPI_GELU_GRAD, bias=bias)
+    zg = ref.clone().requires_grad_()
+    F.gelu(zg).sum().backward()
+    torch.testing.assert_close(gd.double(), zg.grad, **BF16_OUT)
+    torch.testing.assert_close(u2.double(), F.gelu(ref), **BF16_OUT)
+    dzm = ops.gemm(a, w, epilogue=L.EPI_MUL, aux=aux)
+    torch.testing.assert_close(dzm.double(), _gemm_ref(a, w, None) * aux.double(), **BF16_OUT)
     o32 = ops.gemm(a, w, epilogue=L.EPI_STORE_F32)
     torch.testing.assert_close(o32.double(), _gemm_ref(a, w, None), rtol=2e-4, atol=2e-4)
     # dW = dY^T X and dbias over all M rows (512 workgroups, ragged last split), also accumulated onto existing values

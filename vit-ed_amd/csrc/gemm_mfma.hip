@@ -49,8 +49,13 @@ __device__ __forceinline__ void nt_stage_load(const bf16* __restrict__ A, int64_
         const int c = cp ^ C::swz(r);
         int64_t gn = n0 + r;
         gn = gn < N ? gn : N - 1;
-        if constexpr (ASM_DMA) glds16_asm(B + gn * ldb + k0 + c * 8, stage + C::A_BYTES + (wave * RB + i * C::ROWS_PER_DMA) * C::ROW_BYTES);
-        else glds16(B + gn * ldb + k0 + c * 8, stage + C::A_BYTES + (wave * RB + i * C::ROWS_PER_DMA) * C::ROW_BYTES);
+#ifdef NT_DBG_W_BLOCKED      // timing experiment: B read as if stored K-blocked [K/BKT][N][BKT] (every piece 1 KB contiguous)
+        const bf16* bsrc = B + (k0 / BKT) * N * BKT + gn * BKT + c * 8;
+#else
+        const bf16* bsrc = B + gn * ldb + k0 + c * 8;
+#endif
+        if constexpr (ASM_DMA) glds16_asm(bsrc, stage + C::A_BYTES + (wave * RB + i * C::ROWS_PER_DMA) * C::ROW_BYTES);
+        else glds16(bsrc, stage + C::A_BYTES + (wave * RB + i * C::ROWS_PER_DMA) * C::ROW_BYTES);
     }
 }
 
@@ -233,7 +238,9 @@ static int dispatch_nt(const bf16* a, int64_t lda, const bf16* b, int64_t ldb, i
     bool shallow = K <= 512 && N >= 768;
     // measured (M = 65536): the 256-row tile wins 5-10 % on plain-store K = 384 GEMMs with
     // N >= 768 (qkv, kv, fc1) and loses on the register-heavier epilogues, so it is used only there
-    bool tall = EPI == VITED_EPI_STORE && shallow && N >= 768 && M >= 8192;
+    // (round 3, after the streaming stores: the taller tile now also wins on fc1 + GELU' (-8 %) and on dz = . * gelu' (-17 %))
+    constexpr bool tall_epi = EPI == VITED_EPI_STORE || EPI == VITED_EPI_MUL || EPI == VITED_EPI_GELU_GRAD;
+    bool tall = tall_epi && shallow && N >= 768 && M >= 8192;
 #ifdef VITED_TUNING   // experiment builds only: VITED_NT_BK = 32 | 64, VITED_NT_WM = 2 | 4, VITED_NT_STAGES = 3
     static const int force_bk = getenv("VITED_NT_BK") ? atoi(getenv("VITED_NT_BK")) : 0;
     static const int force_wm = getenv("VITED_NT_WM") ? atoi(getenv("VITED_NT_WM")) : 0;
@@ -249,7 +256,8 @@ static int dispatch_nt(const bf16* a, int64_t lda, const bf16* b, int64_t ldb, i
 #endif
     // the three-stage asm-DMA ring (72 KB, 2 workgroups per CU, two stages in flight each) pays on the plain-store 256 x 128 tiles
     // only: qkv 82 -> 78 us, kv 56 -> 54; every other variant loses occupancy to it (BK = 64: 96 KB = one workgroup per CU, +50 %)
-    if (shallow && tall) return launch_nt<EPI, 32, 4, 3>(a, lda, b, ldb, M, N, K, ep, s);
+    if (shallow && tall && EPI == VITED_EPI_STORE) return launch_nt<EPI, 32, 4, 3>(a, lda, b, ldb, M, N, K, ep, s);
+    if (shallow && tall) return launch_nt<EPI, 32, 4>(a, lda, b, ldb, M, N, K, ep, s);
     if (shallow) return launch_nt<EPI, 32, 2>(a, lda, b, ldb, M, N, K, ep, s);
     if (tall) return launch_nt<EPI, 64, 4>(a, lda, b, ldb, M, N, K, ep, s);
     return launch_nt<EPI, 64, 2>(a, lda, b, ldb, M, N, K, ep, s);

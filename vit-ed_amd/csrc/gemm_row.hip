@@ -120,8 +120,13 @@ gemm_row_kernel(const RowArgs a) {
         ar8 = ar8 < a.M ? ar8 : a.M - 1;
         pa8 = a.A + ar8 * a.lda + csrc;
     }
+#ifdef ROW_DBG_W_BLOCKED                      // timing experiment: W read as if stored K-blocked [K/32][384][32] (1 KB contiguous per piece)
+    const bf16* pb = a.W + (int64_t)(wave * 48 + rsub) * 32 + csrc;
+    const int64_t pstep = 16 * 32;
+#else
     const bf16* pb = a.W + (int64_t)(wave * 48 + rsub) * a.ldw + csrc;
     const int64_t pstep = 16 * a.ldw;
+#endif
     const int nsteps = a.K / 32;
     auto issue = [&](int stage_idx) {
         char* dst = smem + (stage_idx & (RW_STAGES - 1)) * R::STAGE_BYTES;
@@ -131,7 +136,11 @@ gemm_row_kernel(const RowArgs a) {
         glds16_asm(pa + ka, dst + wave * 1024);      // (the nt policy on this once-read stream costs 0.95 ms per step: measured, not used)
         if (MT == 9 && wave == 0) glds16_asm(pa8 + ka, dst + 8 * 1024);
 #pragma unroll
+#ifdef ROW_DBG_W_BLOCKED
+        for (int i = 0; i < 3; ++i) glds16_asm(pb + i * pstep + (int64_t)stage_idx * ROW_N * 32, dst + R::A_BYTES + (wave * 3 + i) * 1024);
+#else
         for (int i = 0; i < 3; ++i) glds16_asm(pb + i * pstep + k0, dst + R::A_BYTES + (wave * 3 + i) * 1024);
+#endif
     };
 
     // ---- fragment offsets: row (16 i + fr) / (48 wave + 16 j + fr), k-chunk fq; the swizzle again depends on fr only
