@@ -203,6 +203,8 @@ class LaunchTimer:
             e0.record()
             out = orig(*a, **k)
             e1.record()
+            if out is False:             # linear_bwd_weight_batched: the set is not covered, nothing was launched
+                return out
             gp, ap = self.ops.last_paths()
             self.records.append((label_fn(a, k, gp, ap), flops_fn(a, k), e0, e1, bytes_fn(a, k) if bytes_fn else 0.0))
             return out
@@ -252,6 +254,11 @@ class LaunchTimer:
 
         self._wrap('gemm', gemm_flops, lambda a, k, gp, ap: 'gemm_nt_mfma_kernel' if gp == 2 else 'gemm_portable_kernel', gemm_bytes)
         self._wrap('linear_bwd_weight', tn_flops, lambda a, k, gp, ap: 'gemm_tn_mfma_kernel(+slab/bias sums)' if gp == 2 else 'gemm_tn_portable_kernel', tn_bytes)
+        # a block's weight gradients in one launch (+ one slab-sum launch): items = [(dy [M, N], x [M, K], dw, db | None), ...]
+        self._wrap('linear_bwd_weight_batched', lambda a, k: sum(2.0 * dy.shape[0] * dy.shape[1] * x.shape[1] for dy, x, _dw, _db in a[0]),
+                   lambda a, k, gp, ap: 'gemm_tn_wide_kernel(batched dW + slab sums)',
+                   lambda a, k: float(sum(dy.numel() * dy.element_size() + x.numel() * x.element_size() + 4 * dy.shape[1] * x.shape[1]
+                                          for dy, x, _dw, _db in a[0])))
         self._wrap('attention_fwd', attn_fwd_flops, lambda a, k, gp, ap: 'attn_fwd_mfma' if ap == 2 else 'attn_fwd_portable_kernel', attn_bytes)
         self._wrap('attention_bwd', lambda a, k: 2.5 * attn_fwd_flops(a, k), lambda a, k, gp, ap: 'attn_bwd_mfma' if ap == 2 else 'attn_bwd_portable_kernels',
                    lambda a, k: attn_bytes(a, k, True))
@@ -274,8 +281,8 @@ class LaunchTimer:
             n = a[1].shape[0]
             return float(m * kk * 2 + n * kk * 2 + m * n * (4 + (4 if k.get('dx_in') is not None else 0) + 4 + (2 if k.get('want_lp') else 0)))
 
-        self._wrap('linear_residual_layernorm_fwd', row_flops, lambda a, k, gp, ap: 'gemm_row_kernel(residual+LayerNorm fwd)', row_fwd_bytes)
-        self._wrap('linear_layernorm_bwd', row_flops, lambda a, k, gp, ap: 'gemm_row_kernel(dX+LayerNorm bwd)', row_bwd_bytes)
+        self._wrap('linear_residual_layernorm_fwd', row_flops, lambda a, k, gp, ap: 'gemm_row_kernel', row_fwd_bytes)
+        self._wrap('linear_layernorm_bwd', row_flops, lambda a, k, gp, ap: 'gemm_row_kernel', row_bwd_bytes)
         if hasattr(self.ops, 'mlp_fwd'):
             self._wrap('mlp_fwd', lambda a, k: 4.0 * a[0].shape[0] * a[0].shape[1] * a[3].shape[0], lambda a, k, gp, ap: 'mlp_fwd_fused_kernel')
         return self

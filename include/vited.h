@@ -180,7 +180,7 @@ int vited_linear_bwd_weight_batched(int count, const void* const* dY, const int6
  * :268-272, norm_layer :348): every residual Linear (attn.proj :38, cross_attn.proj :156, timm Mlp fc2) is followed by the next
  * sub-block's LayerNorm, and every Linear that consumes a LayerNorm's output (qkv :34, q :151, kv :152, fc1) is followed, in
  * backward, by that LayerNorm's backward.  These two entries do each pair in ONE kernel so the LayerNorm is not a separate
- * pass over the fp32 residual stream.  bf16 operands, N == 384 (the embed width of every shipped pjs config), K % 32 == 0;
+ * pass over the fp32 residual stream.  bf16 operands, N == 384 (the embed width of every shipped pjs config), K % 64 == 0;
  * vited_linear_layernorm_supported() tells whether a shape is covered - otherwise the caller runs vited_gemm +
  * vited_layernorm_fwd / vited_layernorm_bwd. */
 int vited_linear_layernorm_supported(int64_t M, int64_t N, int64_t K);

@@ -233,7 +233,7 @@ def test_gemm_bench_scale_tiles(vited, gpu, M, N, K):
 # ---------------------------------------------------------------------------------------------
 # row-complete Linear + LayerNorm kernels (gemm_row.hip)
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize('M,K', [(64, 384), (80, 1536), (65 * 8, 384), (1000, 1152), (4096 + 33, 768), (65 * 64, 1536), (16384, 384), (13, 32)])
+@pytest.mark.parametrize('M,K', [(64, 384), (80, 1536), (65 * 8, 384), (1000, 1152), (4096 + 33, 768), (65 * 64, 1536), (16384, 384), (13, 64), (200, 192)])
 def test_linear_residual_layernorm_fwd(vited, gpu, M, K):
     """y = residual + a W^T + b and h = LayerNorm(y) in one kernel against fp64 on the same bf16-rounded operands: ragged M
     (partial last tile, both tile heights: 64-row tiles and the 80-row tiles picked for 65-row batches), every K of the step."""
@@ -267,7 +267,7 @@ def test_linear_residual_layernorm_fwd(vited, gpu, M, K):
     assert torch.equal(inplace, y)
 
 
-@pytest.mark.parametrize('M,K', [(64, 384), (80, 1536), (65 * 8, 1152), (1000, 768), (4096 + 33, 1536), (65 * 64, 384), (16384, 1152)])
+@pytest.mark.parametrize('M,K', [(64, 384), (80, 1536), (65 * 8, 1152), (1000, 768), (4096 + 33, 1536), (65 * 64, 384), (16384, 1152), (13, 64), (300, 192)])
 def test_linear_layernorm_bwd(vited, gpu, M, K):
     """dx = dx_in + LN'(dy Wt^T) with the column sums, one kernel, against fp64 autograd through LayerNorm on the same
     bf16-rounded operands.  d(LayerNorm output) stays fp32 inside the kernel, so it is MORE accurate than the two-kernel form

@@ -35,7 +35,6 @@
 
 #define ROW_N 384
 #define ROW_LD 388      // floats per scratch row: 16-byte aligned rows; 388 mod 32 = 4 spreads the 8-lane groups of ds_write_b128 over the banks
-#define RW_STAGES 4     // a power of two: slot = stage & 3
 
 enum { ROW_MODE_FWD = 0, ROW_MODE_BWD = 1 };
 
@@ -59,15 +58,17 @@ struct RowArgs {
 template <int MT> struct RowCfg {
     static_assert(MT == 8 || MT == 9, "tile heights: 128 or 144 rows");
     static constexpr int BM = 16 * MT;
-    static constexpr int A_BYTES = BM * 64;
-    static constexpr int STAGE_BYTES = A_BYTES + ROW_N * 64;
-    static constexpr int LDS_BYTES = RW_STAGES * STAGE_BYTES;            // 131,072 / 135,168
+    static constexpr int A_BYTES = BM * 128;                             // one K = 64 tile of the A panel: 16 / 18 KB
+    static constexpr int W_BYTES = ROW_N * 128;                          // ... of the whole W panel: 48 KB
+    static constexpr int W_BASE = 3 * A_BYTES;
+    static constexpr int LDS_BYTES = 3 * A_BYTES + 2 * W_BYTES;          // 147,456 / 153,600
+    static constexpr int P0 = (MT + 1) / 2;                              // row tiles of a K-tile's first phase: 4 / 5
     static constexpr int PASS_SUB = MT == 8 ? 4 : 3;                     // 16-row sub-tiles per epilogue pass
     static constexpr int PASS_ROWS = 16 * PASS_SUB;                      // 64 / 48
     static constexpr int NPASS = MT / PASS_SUB;                          // 2 / 3
     static constexpr int ROWS_PER_HALF = PASS_ROWS / 16;                 // rows of a pass per half-wave (16 half-waves): 4 / 3
-    static_assert(LDS_BYTES >= PASS_ROWS * ROW_LD * 4, "epilogue scratch must fit the ring");
-    static_assert(LDS_BYTES >= 16 * 2 * ROW_N * 4, "column-partial combine must fit the ring");
+    static_assert(LDS_BYTES >= PASS_ROWS * ROW_LD * 4, "epilogue scratch must fit the staging buffers");
+    static_assert(LDS_BYTES >= 16 * 2 * ROW_N * 4, "column-partial combine must fit the staging buffers");
 };
 
 __device__ __forceinline__ float row_half_sum(float v) {   // over the 32 lanes of a half-wave
@@ -85,13 +86,11 @@ __device__ __forceinline__ float row_half_sum(float v) {   // over the 32 lanes 
 
 struct RowFwdIn { f32x4 res[3]; };
 struct RowBwdIn { f32x4 x[3], din[3]; float mu, rs; };
-template <int MT> struct RowFrags { bf16x8 a[MT], b[3]; };
 
 template <int MODE, int MT>
 __global__ void __launch_bounds__(512)
 gemm_row_kernel(const RowArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    using C = NtCfg<32>;
     using R = RowCfg<MT>;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -103,126 +102,153 @@ gemm_row_kernel(const RowArgs a) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // ---- LDS-DMA roles: a piece = 16 rows x 64 B = one wave-instruction.  Wave w stages A piece w (wave 0 also piece 8 when
-    // MT = 9) and W pieces 3 w .. 3 w + 2 (its own 48 columns).  Lane (rsub, cp) lands at row rsub, 16-byte slot cp, and fetches
-    // source chunk cp ^ swz(row): the swizzle only depends on (row >> 2) & 3 = (rsub >> 2) & 3 for every piece.
-    const int rsub = lane >> 2, cp = lane & 3;
-    const int csrc = (cp ^ C::swz(rsub)) * 8;
-    int64_t ar = m0 + wave * 16 + rsub;
+    // ---- main loop: K = 64 tiles, phases gated by workgroup barriers, the two wave groups one slot apart -------------------------
+    // LDS: three A buffers (BM rows x 128 B, tile t in buffer t % 3) + two W buffers (384 rows x 128 B, tile t in buffer t & 1).
+    // Every LDS-DMA piece is 8 rows x 128 B: FULL cache lines (16 rows x 64 B pieces cost the vector-memory path twice the line
+    // look-ups for the same bytes: staging alone ran 1.6 x faster with full lines).  Lane (r8, c8) lands at
+    // row r8, 16-byte slot c8 of its piece and fetches source chunk c8 ^ swz(row), swz(row) = (row >> 1) & 7 = 4 (piece & 1) + (r8 >> 1).
+    //
+    // A wave's K-tile is two PHASES (row tiles 0 .. P0-1, then P0 .. MT-1; 3 column tiles x 2 k-halves each), and each phase is two
+    // SLOTS separated by workgroup barriers: L = fragment reads (ds_read_b128) + this slot's share of the LDS-DMA, M = the MFMAs.
+    // Group 1 (waves 4-7) runs one slot behind group 0 (waves 0-3), and waves w / w + 4 share a SIMD: in every slot each SIMD has
+    // one wave in its MFMA cluster and one wave loading (the 8-phase schedule of the CDNA4 guide, section 5, on a 128 x 384 tile).
+    // Global slot s = 4 t + k for group 0, one later for group 1.  Issue schedule (16 pieces = 4 per wave of the issuing group per
+    // L slot; W tile = parts 0..2 of 128 rows):
+    //     slot 4t   (g0): W(t+1) part 1      slot 4t+1 (g1): W(t+1) part 2      slot 4t+2 (g0): A(t+2)      slot 4t+3 (g1): W(t+2) part 0
+    // WAR: W buffer t & 1 was last read in slot 4t+1 (g1's phase 0; retired by its lgkmcnt(0) in slot 4t+2, whose barrier certifies
+    // it) -> rewritten from slot 4t+3; A buffer (t+2) % 3 = (t-1) % 3 was last read in slot 4t-1 -> rewritten in slot 4t+2.
+    // RAW: every wave waits (counted vmcnt) for its own pieces of tile t+1 before the barrier that ends slot 4t+3; group 0 reads
+    // tile t+1 in slot 4t+4.  The youngest part of W(t+1) then had two slots to land (it is L2-resident), A(t+1) six.
+    const int grp = wave >> 2, u = wave & 3;
+    const int nt = a.K / 64;
+    const int r8 = lane >> 3, c8 = lane & 7;
+    const int cs_even = (c8 ^ (r8 >> 1)) * 8, cs_odd = (c8 ^ (r8 >> 1) ^ 4) * 8;
+    // group 0 stages A: wave u pieces 4 u .. 4 u + 3 (+ piece 16 + u for u < 2 when MT = 9)
+    const bf16* pa[4];
+    const bf16* pax = nullptr;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int64_t ar = m0 + 32 * u + 8 * j + r8;
 #ifdef ROW_DBG_A_RESIDENT                    // timing experiment: every workgroup stages the FIRST tile's rows (A served by L2, not HBM)
-    ar = wave * 16 + rsub;
+        ar -= m0;
 #endif
-    ar = ar < a.M ? ar : a.M - 1;            // rows past M are staged from the last row and never stored
-    const bf16* pa = a.A + ar * a.lda + csrc;
-    const bf16* pa8 = pa;
-    if (MT == 9) {
-        int64_t ar8 = m0 + 128 + rsub;
-        ar8 = ar8 < a.M ? ar8 : a.M - 1;
-        pa8 = a.A + ar8 * a.lda + csrc;
+        ar = ar < a.M ? ar : a.M - 1;        // rows past M are staged from the last row and never stored
+        pa[j] = a.A + ar * a.lda + ((j & 1) ? cs_odd : cs_even);
     }
-#ifdef ROW_DBG_W_BLOCKED                      // timing experiment: W read as if stored K-blocked [K/32][384][32] (1 KB contiguous per piece)
-    const bf16* pb = a.W + (int64_t)(wave * 48 + rsub) * 32 + csrc;
-    const int64_t pstep = 16 * 32;
-#else
-    const bf16* pb = a.W + (int64_t)(wave * 48 + rsub) * a.ldw + csrc;
-    const int64_t pstep = 16 * a.ldw;
-#endif
-    const int nsteps = a.K / 32;
-    auto issue = [&](int stage_idx) {
-        char* dst = smem + (stage_idx & (RW_STAGES - 1)) * R::STAGE_BYTES;
-        const int k0 = stage_idx * 32;
-        const int seg = k0 / a.seg_k;                                         // scalar: which [M, seg_k] tensor this K-step reads
+    const bool a_extra = MT == 9 && grp == 0 && u < 2;
+    if (MT == 9) {
+        int64_t ar = m0 + 128 + 8 * u + r8;
+        ar = ar < a.M ? ar : a.M - 1;
+        pax = a.A + ar * a.lda + ((u & 1) ? cs_odd : cs_even);
+    }
+    const bf16* pw_even = a.W + (int64_t)(32 * u + r8) * a.ldw + cs_even;
+    const bf16* pw_odd = a.W + (int64_t)(32 * u + r8) * a.ldw + cs_odd;
+    auto issue_a = [&](int t) {
+        if (t >= nt) return;
+        char* dst = smem + (t % 3) * R::A_BYTES;
+        const int k0 = t * 64;
+        const int seg = k0 / a.seg_k;                                         // scalar: which [M, seg_k] tensor this K-tile reads
         const int64_t ka = (int64_t)seg * a.seg_stride + (k0 - seg * a.seg_k);
-        glds16_asm(pa + ka, dst + wave * 1024);      // (the nt policy on this once-read stream costs 0.95 ms per step: measured, not used)
-        if (MT == 9 && wave == 0) glds16_asm(pa8 + ka, dst + 8 * 1024);
 #pragma unroll
-#ifdef ROW_DBG_W_BLOCKED
-        for (int i = 0; i < 3; ++i) glds16_asm(pb + i * pstep + (int64_t)stage_idx * ROW_N * 32, dst + R::A_BYTES + (wave * 3 + i) * 1024);
-#else
-        for (int i = 0; i < 3; ++i) glds16_asm(pb + i * pstep + k0, dst + R::A_BYTES + (wave * 3 + i) * 1024);
-#endif
+        for (int j = 0; j < 4; ++j) glds16_asm(pa[j] + ka, dst + (4 * u + j) * 1024);
+        if (a_extra) glds16_asm(pax + ka, dst + (16 + u) * 1024);
     };
-
-    // ---- fragment offsets: row (16 i + fr) / (48 wave + 16 j + fr), k-chunk fq; the swizzle again depends on fr only
+    auto issue_w = [&](int t, int part) {
+        if (t >= nt) return;
+        char* dst = smem + R::W_BASE + (t & 1) * R::W_BYTES + (16 * part + 4 * u) * 1024;
+        const int64_t off = (int64_t)(128 * part) * a.ldw + t * 64;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16_asm(((j & 1) ? pw_odd : pw_even) + off + (int64_t)(8 * j) * a.ldw, dst + j * 1024);
+    };
+    // fragments: row (16 i + fr) of A / row (48 wave + 16 j + fr) of W, k-half kk -> 16-byte chunk 4 kk + fq; swz(row) = (fr >> 1) & 7
     const int fr = lane & 15, fq = lane >> 4;
-    const int aoff = C::off(fr, fq);
-    const int boff = R::A_BYTES + wave * 48 * 64 + C::off(fr, fq);
-    auto read_frags = [&](RowFrags<MT>& f, const char* st) {
+    const int loff0 = fr * 128 + ((fq ^ ((fr >> 1) & 7)) << 4), loff1 = fr * 128 + (((4 + fq) ^ ((fr >> 1) & 7)) << 4);
+    bf16x8 fa[R::P0][2], fb[3][2];
+    auto read_b = [&](int t) {
+        const char* wb = smem + R::W_BASE + (t & 1) * R::W_BYTES + wave * 48 * 128;
 #pragma unroll
-        for (int i = 0; i < MT; ++i) f.a[i] = *(const bf16x8*)(st + aoff + i * 1024);
-#pragma unroll
-        for (int j = 0; j < 3; ++j) f.b[j] = *(const bf16x8*)(st + boff + j * 1024);
-    };
-
-    // PER = LDS-DMA instructions per stage of THIS wave (wave-uniform): 4, or 5 for wave 0 of the 144-row tile
-    auto mainloop = [&](auto per_tag) {
-        constexpr int PER = decltype(per_tag)::value;
-        // wait until this wave's pieces of stage `idx` have landed: the stages issued after it stay in flight
-        auto wait_landed = [&](int idx) {
-            const int last = nsteps - 1 < idx + RW_STAGES - 2 ? nsteps - 1 : idx + RW_STAGES - 2;
-            const int later = last - idx;
-            if (later >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
-            else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        };
-        // The barrier of step t certifies stage t + 1 (landed) and frees stage t's slot (every wave holds its stage-t fragments in
-        // registers by then): the fragment reads of step t + 1 are issued UNDER the MFMAs of step t.
-        auto step = [&](int t, const RowFrags<MT>& cur, RowFrags<MT>& nxt) {
-            if (t + 1 < nsteps) wait_landed(t + 1);
-            __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0), as the builtin: hipcc's own bookkeeping then knows the reads retired
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            const bool dma_first = wave >= 4;     // waves w and w + 4 share a SIMD: one issues DMA while the other's MFMAs hold the pipe
-#ifndef ROW_DBG_NO_DMA
-            if (dma_first && t + RW_STAGES < nsteps) issue(t + RW_STAGES);     // into the slot stage t has just left
-#endif
-#ifndef ROW_DBG_NO_READS
-            if (t + 1 < nsteps) read_frags(nxt, smem + ((t + 1) & (RW_STAGES - 1)) * R::STAGE_BYTES);
-#endif
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < 3; ++j)
-#pragma unroll
-                for (int i = 0; i < MT; ++i) {  // transposed product: lane holds row (16 i + fr), columns 48 wave + 16 j + 4 fq + (0..3)
-#ifdef ROW_DBG_NO_MFMA
-                    asm volatile("" ::"v"(cur.b[j]), "v"(cur.a[i]));
-#else
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur.b[j], cur.a[i], acc[i][j], 0, 0, 0);
-#endif
-                }
-            __builtin_amdgcn_sched_barrier(0);
-#ifndef ROW_DBG_NO_DMA
-            if (!dma_first && t + RW_STAGES < nsteps) issue(t + RW_STAGES);
-#endif
-        };
-#pragma unroll
-        for (int pre = 0; pre < RW_STAGES; ++pre)
-            if (nsteps > pre) issue(pre);
-        {
-            const int later = nsteps - 1 < RW_STAGES - 1 ? nsteps - 1 : RW_STAGES - 1;
-            if (later >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PER) : "memory");
-            else if (later == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
-            else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-        }
-        RowFrags<MT> fa, fb;
-        read_frags(fa, smem);
-        for (int t = 0; t < nsteps; t += 2) {
-            step(t, fa, fb);
-            if (t + 1 < nsteps) step(t + 1, fb, fa);
+        for (int j = 0; j < 3; ++j) {
+            fb[j][0] = *(const bf16x8*)(wb + j * 2048 + loff0);
+            fb[j][1] = *(const bf16x8*)(wb + j * 2048 + loff1);
         }
     };
-    if (MT == 9 && wave == 0) mainloop(std::integral_constant<int, 5>{});
-    else mainloop(std::integral_constant<int, 4>{});
-#ifdef ROW_DBG_NO_EPI                        // timing experiment: main loop only
+    auto read_a = [&](int t, auto i0_tag, auto n_tag) {
+        constexpr int I0 = decltype(i0_tag)::value, NR = decltype(n_tag)::value;
+        const char* ab = smem + (t % 3) * R::A_BYTES + I0 * 2048;
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+        for (int i = 0; i < NR; ++i) {
+            fa[i][0] = *(const bf16x8*)(ab + i * 2048 + loff0);
+            fa[i][1] = *(const bf16x8*)(ab + i * 2048 + loff1);
+        }
+    };
+    auto mfmas = [&](auto i0_tag, auto n_tag) {
+        constexpr int I0 = decltype(i0_tag)::value, NR = decltype(n_tag)::value;
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int j = 0; j < 3; ++j) asm volatile("" ::"v"(acc[i][j]));
-    return;
-#endif
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < NR; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)   // transposed product: lane holds row (16 i + fr), columns 48 wave + 16 j + 4 fq + (0..3)
+                    acc[I0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][kk], fa[i][kk], acc[I0 + i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto barrier = [&]() {
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    // this wave's pieces of every tile up to `upto` have landed; `younger` = whether one later group of its pieces stays in flight
+    auto certify = [&](bool younger) {
+        if (!younger) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (a_extra) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using IP0 = std::integral_constant<int, R::P0>;
+    using IP1 = std::integral_constant<int, MT - R::P0>;
+    if (grp == 0) {
+        issue_a(0);
+        issue_w(0, 1);
+        issue_a(1);
+        certify(nt > 1);                     // A(0), W(0) part 1 landed; A(1) may still fly
+        barrier();
+        for (int t = 0; t < nt; ++t) {
+            read_b(t);                                        // slot 4t: L of phase 0
+            read_a(t, I0{}, IP0{});
+            issue_w(t + 1, 1);
+            barrier();
+            mfmas(I0{}, IP0{});                               // slot 4t+1: M of phase 0
+            barrier();
+            read_a(t, IP0{}, IP1{});                          // slot 4t+2: L of phase 1
+            issue_a(t + 2);
+            barrier();
+            mfmas(IP0{}, IP1{});                              // slot 4t+3: M of phase 1
+            certify(t + 2 < nt);                              // A(t+1), W(t+1) part 1 landed; A(t+2) may still fly
+            barrier();
+        }
+        barrier();                                            // group 1's last M slot
+    } else {
+        issue_w(0, 0);
+        issue_w(0, 2);
+        issue_w(1, 0);
+        certify(nt > 1);                     // W(0) parts 0 and 2 landed; W(1) part 0 may still fly
+        barrier();
+        barrier();                                            // one slot behind group 0
+        for (int t = 0; t < nt; ++t) {
+            read_b(t);                                        // slot 4t+1
+            read_a(t, I0{}, IP0{});
+            issue_w(t + 1, 2);
+            barrier();
+            mfmas(I0{}, IP0{});                               // slot 4t+2
+            barrier();
+            read_a(t, IP0{}, IP1{});                          // slot 4t+3
+            issue_w(t + 2, 0);
+            certify(t + 2 < nt);                              // W(t+1) parts 0 and 2 landed; W(t+2) part 0 may still fly
+            barrier();
+            mfmas(IP0{}, IP1{});                              // slot 4t+4
+            barrier();
+        }
+    }
 #ifdef ROW_DBG_NO_EPI                        // timing experiment: main loop only
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -399,7 +425,7 @@ static inline int row_mt(int64_t M) {
 
 static inline int64_t row_tiles(int64_t M) { return ceil_div64(M, 16 * row_mt(M)); }
 
-static bool row_shape_ok(int64_t M, int64_t N, int64_t K) { return N == ROW_N && K >= 32 && K % 32 == 0 && K <= (1 << 20) && M >= 1 && M < ((int64_t)1 << 31); }
+static bool row_shape_ok(int64_t M, int64_t N, int64_t K) { return N == ROW_N && K >= 64 && K % 64 == 0 && K <= (1 << 20) && M >= 1 && M < ((int64_t)1 << 31); }
 
 extern "C" int vited_linear_layernorm_supported(int64_t M, int64_t N, int64_t K) { return row_shape_ok(M, N, K) ? 1 : 0; }
 
@@ -457,7 +483,7 @@ static int linear_layernorm_bwd_impl(const void* dy, int64_t lddy, int64_t seg_k
     if ((dgamma == nullptr) != (dbeta == nullptr)) return VITED_ERR_BAD_ARG;
     if (seg_k <= 0 || K % seg_k || lddy < seg_k || ldwt < K || ldx < N || dx_out_ld < N || (dx_in && dx_in_ld < N) || (dx_lp && dx_lp_ld < N))
         return VITED_ERR_BAD_ARG;
-    if (!row_shape_ok(M, N, K) || seg_k % 32 || (seg_stride & 7)) return VITED_ERR_UNSUPPORTED;
+    if (!row_shape_ok(M, N, K) || seg_k % 64 || (seg_stride & 7)) return VITED_ERR_UNSUPPORTED;
     if ((lddy & 7) || (ldwt & 7) || (ldx & 3) || (dx_out_ld & 3) || (dx_in && (dx_in_ld & 3)) || (dx_lp && (dx_lp_ld & 3))) return VITED_ERR_UNSUPPORTED;
     if (!al16(dy) || !al16(wt) || !al16(x) || !al16(gamma) || !al16(dx_in) || !al16(dx_out) || ((uintptr_t)dx_lp & 7)) return VITED_ERR_BAD_ARG;
     if (!workspace || workspace_bytes < vited_linear_layernorm_bwd_workspace_bytes(M, N)) return VITED_ERR_WORKSPACE;
