@@ -144,6 +144,9 @@ gemm_row_kernel(const RowArgs a) {
     const bf16* pw_even = a.W + (int64_t)(32 * u + r8) * a.ldw + cs_even;
     const bf16* pw_odd = a.W + (int64_t)(32 * u + r8) * a.ldw + cs_odd;
     auto issue_a = [&](int t) {
+#ifdef ROW_DBG_NO_DMA
+        return;
+#endif
         if (t >= nt) return;
         char* dst = smem + (t % 3) * R::A_BYTES;
         const int k0 = t * 64;
@@ -154,6 +157,9 @@ gemm_row_kernel(const RowArgs a) {
         if (a_extra) glds16_asm(pax + ka, dst + (16 + u) * 1024);
     };
     auto issue_w = [&](int t, int part) {
+#ifdef ROW_DBG_NO_DMA
+        return;
+#endif
         if (t >= nt) return;
         char* dst = smem + R::W_BASE + (t & 1) * R::W_BYTES + (16 * part + 4 * u) * 1024;
         const int64_t off = (int64_t)(128 * part) * a.ldw + t * 64;
@@ -163,8 +169,11 @@ gemm_row_kernel(const RowArgs a) {
     // fragments: row (16 i + fr) of A / row (48 wave + 16 j + fr) of W, k-half kk -> 16-byte chunk 4 kk + fq; swz(row) = (fr >> 1) & 7
     const int fr = lane & 15, fq = lane >> 4;
     const int loff0 = fr * 128 + ((fq ^ ((fr >> 1) & 7)) << 4), loff1 = fr * 128 + (((4 + fq) ^ ((fr >> 1) & 7)) << 4);
-    bf16x8 fa[R::P0][2], fb[3][2];
+    bf16x8 fa[R::P0][2] = {}, fb[3][2] = {};
     auto read_b = [&](int t) {
+#ifdef ROW_DBG_NO_READS
+        return;
+#endif
         const char* wb = smem + R::W_BASE + (t & 1) * R::W_BYTES + wave * 48 * 128;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
@@ -174,6 +183,9 @@ gemm_row_kernel(const RowArgs a) {
     };
     auto read_a = [&](int t, auto i0_tag, auto n_tag) {
         constexpr int I0 = decltype(i0_tag)::value, NR = decltype(n_tag)::value;
+#ifdef ROW_DBG_NO_READS
+        return;
+#endif
         const char* ab = smem + (t % 3) * R::A_BYTES + I0 * 2048;
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
@@ -190,7 +202,11 @@ gemm_row_kernel(const RowArgs a) {
             for (int i = 0; i < NR; ++i)
 #pragma unroll
                 for (int j = 0; j < 3; ++j)   // transposed product: lane holds row (16 i + fr), columns 48 wave + 16 j + 4 fq + (0..3)
+#ifdef ROW_DBG_NO_MFMA
+                    asm volatile("" ::"v"(fb[j][kk]), "v"(fa[i][kk]));
+#else
                     acc[I0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][kk], fa[i][kk], acc[I0 + i][j], 0, 0, 0);
+#endif
         __builtin_amdgcn_s_setprio(0);
     };
     auto barrier = [&]() {
@@ -198,10 +214,21 @@ gemm_row_kernel(const RowArgs a) {
         asm volatile("" ::: "memory");
     };
     // this wave's pieces of every tile up to `upto` have landed; `younger` = whether one later group of its pieces stays in flight
-    auto certify = [&](bool younger) {
-        if (!younger) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (a_extra) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    // (wait and barrier are ONE asm statement: as two, hipcc moved the wait a slot earlier - above the previous barrier and the MFMA
+    // cluster, where it stalls on pieces issued two slots before)
+    auto certify_barrier = [&](bool younger) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (!younger) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        else if (a_extra) asm volatile("s_waitcnt vmcnt(5)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // The fragment reads of an L slot retire INSIDE it (under the partner group's MFMAs): the M slot then opens with its first MFMA
+    // instead of the reads' latency (compute-only loop 60 -> ?? us at K = 1536).
+    auto landed = [&]() {
+#ifndef ROW_DBG_LATE_LGKM
+        __builtin_amdgcn_s_waitcnt(0xc07f);       // lgkmcnt(0)
+#endif
     };
     using I0 = std::integral_constant<int, 0>;
     using IP0 = std::integral_constant<int, R::P0>;
@@ -210,41 +237,41 @@ gemm_row_kernel(const RowArgs a) {
         issue_a(0);
         issue_w(0, 1);
         issue_a(1);
-        certify(nt > 1);                     // A(0), W(0) part 1 landed; A(1) may still fly
-        barrier();
+        certify_barrier(nt > 1);             // A(0), W(0) part 1 landed; A(1) may still fly
         for (int t = 0; t < nt; ++t) {
             read_b(t);                                        // slot 4t: L of phase 0
             read_a(t, I0{}, IP0{});
             issue_w(t + 1, 1);
+            landed();
             barrier();
             mfmas(I0{}, IP0{});                               // slot 4t+1: M of phase 0
             barrier();
             read_a(t, IP0{}, IP1{});                          // slot 4t+2: L of phase 1
             issue_a(t + 2);
+            landed();
             barrier();
             mfmas(IP0{}, IP1{});                              // slot 4t+3: M of phase 1
-            certify(t + 2 < nt);                              // A(t+1), W(t+1) part 1 landed; A(t+2) may still fly
-            barrier();
+            certify_barrier(t + 2 < nt);                      // A(t+1), W(t+1) part 1 landed; A(t+2) may still fly
         }
         barrier();                                            // group 1's last M slot
     } else {
         issue_w(0, 0);
         issue_w(0, 2);
         issue_w(1, 0);
-        certify(nt > 1);                     // W(0) parts 0 and 2 landed; W(1) part 0 may still fly
-        barrier();
+        certify_barrier(nt > 1);             // W(0) parts 0 and 2 landed; W(1) part 0 may still fly
         barrier();                                            // one slot behind group 0
         for (int t = 0; t < nt; ++t) {
             read_b(t);                                        // slot 4t+1
             read_a(t, I0{}, IP0{});
             issue_w(t + 1, 2);
+            landed();
             barrier();
             mfmas(I0{}, IP0{});                               // slot 4t+2
             barrier();
             read_a(t, IP0{}, IP1{});                          // slot 4t+3
             issue_w(t + 2, 0);
-            certify(t + 2 < nt);                              // W(t+1) parts 0 and 2 landed; W(t+2) part 0 may still fly
-            barrier();
+            landed();
+            certify_barrier(t + 2 < nt);                      // W(t+1) parts 0 and 2 landed; W(t+2) part 0 may still fly
             mfmas(IP0{}, IP1{});                              // slot 4t+4
             barrier();
         }
