@@ -659,31 +659,23 @@ gemm_tn_wide_kernel(const TwBatch batch, float* __restrict__ out_base, float* __
         xb_hi[j] = base + r_hi * 256 + ((ch ^ f_hi) << 4) + 8 * (p & 1);
     }
 
-    // Pipeline: the barrier of step t certifies stage t + 1 (landed) and frees stage t's slot (every wave holds its stage-t
-    // fragments in registers by then), so the fragment reads of step t + 1 are issued UNDER the MFMAs of step t and the MFMAs of
-    // consecutive steps run back to back: no LDS latency and no DMA issue on the critical path between two barriers.
-    auto step = [&](int t, const TwFrags& cur, TwFrags& nxt) {
-        if (t + 1 < nsteps) wait_landed(t + 1);
-        // the builtin (not inline asm) so that hipcc's own waitcnt bookkeeping knows the fragment reads have retired: with the asm
-        // form it re-waits for them in front of the MFMAs, behind the NEXT step's 20 reads (lgkmcnt saturates at 15)
-        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        // The two waves of a SIMD (w and w + 4) take the step's two jobs in opposite order - one issues the next stage's DMA
-        // (address VALU + 4 LDS-DMA pieces) while the other's 24 MFMAs hold the matrix pipe, then they swap - instead of both
-        // issuing DMA together and then queueing on the MFMA pipe.
-        const bool dma_first = (wave >> 2) != 0;
-#ifndef TW_DBG_NO_DMA
-        if (dma_first && t + TW_STAGES < nsteps) issue(t + TW_STAGES);     // into the slot stage t has just left
-#endif
-#ifdef TW_DBG_DMA_ONLY
-        if (!dma_first && t + TW_STAGES < nsteps) issue(t + TW_STAGES);
-        return;
-#endif
+    // Pipeline (round 3: the slot schedule of gemm_row.hip).  A step = one 32-row stage = two SLOTS separated by workgroup barriers:
+    // L = the step's 20 transposed fragment reads + this wave's 4 LDS-DMA pieces of stage t + 3, M = its 24 MFMAs.  Group 1 (waves
+    // 4-7, the lower 64 n-rows' partners on each SIMD) runs one slot behind group 0, so every SIMD always has one wave in its MFMA
+    // cluster and one wave loading.  Stage t is read in slots 2t (group 0) and 2t + 1 (group 1), both retired inside their slot:
+    // its ring slot is rewritten (stage t + 4) from slot 2t + 2; every wave certifies its pieces of stage t + 1 (counted vmcnt,
+    // two later stages stay in flight) before the barrier that ends slot 2t + 1.
+    auto slot_l = [&](int t, TwFrags& f) {
 #ifndef TW_DBG_NO_READS
-        if (t + 1 < nsteps) tw_read_frags(nxt, smem + ((t + 1) & (TW_STAGES - 1)) * TW_STAGE_BYTES, ya_lo, ya_hi, xb_lo, xb_hi);
+        tw_read_frags(f, smem + (t & (TW_STAGES - 1)) * TW_STAGE_BYTES, ya_lo, ya_hi, xb_lo, xb_hi);
 #endif
-        __builtin_amdgcn_sched_barrier(0);
+#ifndef TW_DBG_NO_DMA
+        if (t + TW_STAGES - 1 < nsteps) issue(t + TW_STAGES - 1);      // into the slot stage t - 1 left a slot ago
+#endif
+        __builtin_amdgcn_s_waitcnt(0xc07f);       // lgkmcnt(0): the reads retire inside the slot, under the partner group's MFMAs
+    };
+    auto slot_m = [&](const TwFrags& cur) {
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int j = 0; j < 6; ++j)
 #pragma unroll
@@ -694,10 +686,7 @@ gemm_tn_wide_kernel(const TwBatch batch, float* __restrict__ out_base, float* __
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur.b[j], cur.a[i], acc[i][j], 0, 0, 0);
 #endif
             }
-        __builtin_amdgcn_sched_barrier(0);
-#ifndef TW_DBG_NO_DMA
-        if (!dma_first && t + TW_STAGES < nsteps) issue(t + TW_STAGES);
-#endif
+        __builtin_amdgcn_s_setprio(0);
         if (with_bias && kc0 == 0) {
             typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
             const bf16x2_t one2 = {(__bf16)1.0f, (__bf16)1.0f};
@@ -709,37 +698,42 @@ gemm_tn_wide_kernel(const TwBatch batch, float* __restrict__ out_base, float* __
             }
         }
     };
+    auto barrier = [&]() {
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    // this wave's pieces of stage idx have landed (stages idx + 1 .. issued so far stay in flight), ragged rows zeroed; then the barrier
+    auto certify_barrier = [&](int idx) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (idx < nsteps) {
+            wait_landed(idx);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the zero fill of a ragged stage
+        }
+        barrier();
+    };
 
     if (nsteps > 0) {
 #pragma unroll
-        for (int pre = 0; pre < TW_STAGES; ++pre)
+        for (int pre = 0; pre < TW_STAGES - 1; ++pre)
             if (nsteps > pre) issue(pre);
-        // stage 0: landed for this wave, then for all
-        {
-            const int later = (nsteps - 1 < TW_STAGES - 1 ? nsteps - 1 : TW_STAGES - 1);
-            if (later >= 4 && TW_STAGES > 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * TW_PER) : "memory");
-            else if (later >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * TW_PER) : "memory");
-            else if (later == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * TW_PER) : "memory");
-            else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TW_PER) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (32 > rows_here) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int r = rbase + i * 4 + rsub;
-                    if (r >= rows_here) *(f32x4*)(smem + panel * TW_PANEL_BYTES + r * 256 + cp * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
+        certify_barrier(0);
+        TwFrags f;
+        if (wr == 0) {
+            for (int t = 0; t < nsteps; ++t) {
+                slot_l(t, f);                   // slot 2t
+                barrier();
+                slot_m(f);                      // slot 2t + 1
+                certify_barrier(t + 1);
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-        }
-        TwFrags fa, fb;
-#ifndef TW_DBG_DMA_ONLY
-        tw_read_frags(fa, smem, ya_lo, ya_hi, xb_lo, xb_hi);
-#endif
-        for (int t = 0; t < nsteps; t += 2) {
-            step(t, fa, fb);
-            if (t + 1 < nsteps) step(t + 1, fb, fa);
+            barrier();                          // group 1's last M slot
+        } else {
+            barrier();                          // one slot behind group 0
+            for (int t = 0; t < nsteps; ++t) {
+                slot_l(t, f);                   // slot 2t + 1
+                certify_barrier(t + 1);
+                slot_m(f);                      // slot 2t + 2
+                barrier();
+            }
         }
     }
 
