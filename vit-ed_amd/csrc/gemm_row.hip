@@ -393,11 +393,23 @@ gemm_row_kernel(const RowArgs a) {
 #pragma unroll
     for (int p = 0; p < R::NPASS; ++p) {
         const int64_t mp = m0 + p * R::PASS_ROWS;
+#ifndef ROW_EPI_ONE_AHEAD
+        // ALL of this half-wave's rows of the pass are requested before the dump and its two barriers: a half-wave is one of only
+        // 16 per CU, and with one row (1.5 - 3 KB) in flight each the epilogue ran at the latency-bound ~5 TB/s, not the HBM rate
+        RowFwdIn fin[R::ROWS_PER_HALF];
+        RowBwdIn bin[R::ROWS_PER_HALF];
+#pragma unroll
+        for (int k = 0; k < R::ROWS_PER_HALF; ++k) {
+            if (MODE == ROW_MODE_FWD) load_fwd(fin[k], mp + hw + 16 * k);
+            else load_bwd(bin[k], mp + hw + 16 * k);
+        }
+#else
         RowFwdIn fcur, fnxt;
         RowBwdIn bcur, bnxt;
         // the first row's operands travel under the dump and its two barriers
         if (MODE == ROW_MODE_FWD) load_fwd(fcur, mp + hw);
         else load_bwd(bcur, mp + hw);
+#endif
         __syncthreads();       // every wave is done with the LDS (main loop's last stage / the previous pass's rows)
 #pragma unroll
         for (int ii = 0; ii < R::PASS_SUB; ++ii) {
@@ -409,6 +421,10 @@ gemm_row_kernel(const RowArgs a) {
 #pragma unroll
         for (int k = 0; k < R::ROWS_PER_HALF; ++k) {
             const int r = hw + 16 * k;
+#ifndef ROW_EPI_ONE_AHEAD
+            if (MODE == ROW_MODE_FWD) row_fwd(fin[k], r, mp + r);
+            else row_bwd(bin[k], r, mp + r);
+#else
             const bool more = k + 1 < R::ROWS_PER_HALF;
             if (MODE == ROW_MODE_FWD) {
                 if (more) load_fwd(fnxt, mp + r + 16);
@@ -419,6 +435,7 @@ gemm_row_kernel(const RowArgs a) {
                 row_bwd(bcur, r, mp + r);
                 if (more) bcur = bnxt;
             }
+#endif
         }
     }
 
