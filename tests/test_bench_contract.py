@@ -27,7 +27,7 @@ def test_flag_defaults(monkeypatch):
 
 def test_committed_pmc_summary_covers_the_dominant_kernel_classes():
     bench = _bench()
-    for cls in ('gemm_nt_mfma_kernel', 'gemm_tn_wide_kernel', 'layernorm_bwd_kernel'):
+    for cls in ('gemm_nt_mfma_kernel', 'gemm_tn_wide_kernel', 'gemm_row_kernel'):
         t = bench.pmc_traffic(cls)
         assert t['traffic'] and t['traffic'] > 1e6, cls          # bytes per launch
     assert bench.pmc_traffic('no_such_kernel') == {'traffic': None}
