@@ -21,6 +21,7 @@ ops, L = v.ops, v._lib
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--reps', type=int, default=10)
+    ap.add_argument('--rows', type=int, nargs='*', default=[65536, 66560])
     a = ap.parse_args()
     dev = torch.device('cuda:0')
     g = torch.Generator(device='cpu').manual_seed(0)
@@ -42,7 +43,7 @@ def main():
 
     N = 384
     print(f'{"shape":28s} {"two kernels":>12s} {"fused":>9s}   GB/s (fused, algorithmic)')
-    for M in (65536, 66560):
+    for M in a.rows:
         gamma, beta, bias = 1.0 + rnd(N, scale=0.1), rnd(N, scale=0.1), rnd(N, scale=0.1)
         res = rnd(M, N)
         mean, rstd = rnd(M, scale=0.1), 1.0 + rnd(M, scale=0.1).abs()
