@@ -27,7 +27,7 @@ json.loads(line)
 open(os.path.join(dst, f'{tag}_bench_n1.json'), 'w').write(line + '\n')
 
 # 2. kernel stats (rocprofv3 --kernel-trace --stats)
-stats = sorted(glob.glob(os.path.join(src, 'stats', '*', '*_kernel_stats.csv')))[-1]
+stats = max(glob.glob(os.path.join(src, 'stats', '*', '*_kernel_stats.csv')), key=os.path.getmtime)   # the latest collection
 rows = list(csv.DictReader(open(stats)))
 with open(os.path.join(dst, f'{tag}_bench_kernel_stats.csv'), 'w') as f:
     f.write('# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline  (MI355X, hipGraph mode;\n')
@@ -39,7 +39,7 @@ with open(os.path.join(dst, f'{tag}_bench_kernel_stats.csv'), 'w') as f:
 
 # 3. HBM traffic per kernel from the two --pmc passes
 def pmc(dirname, counter):
-    files = sorted(glob.glob(os.path.join(src, dirname, '*', '*_counter_collection.csv')))
+    files = sorted(glob.glob(os.path.join(src, dirname, '*', '*_counter_collection.csv')), key=os.path.getmtime)
     acc = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(files[-1])):
         if r.get('Counter_Name') != counter:
