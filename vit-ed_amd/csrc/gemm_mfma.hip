@@ -39,8 +39,9 @@ __device__ __forceinline__ void nt_stage_load(const bf16* __restrict__ A, int64_
         const int c = cp ^ C::swz(r);
         int64_t gm = m0 + r;
         gm = gm < M ? gm : M - 1;
-        if constexpr (ASM_DMA) glds16_asm(A + gm * lda + k0 + c * 8, stage + (wave * 32 + i * C::ROWS_PER_DMA) * C::ROW_BYTES);
-        else glds16(A + gm * lda + k0 + c * 8, stage + (wave * 32 + i * C::ROWS_PER_DMA) * C::ROW_BYTES);
+        const bf16* asrc = A + gm * lda + k0 + c * 8;
+        if constexpr (ASM_DMA) glds16_asm(asrc, stage + (wave * 32 + i * C::ROWS_PER_DMA) * C::ROW_BYTES);
+        else glds16(asrc, stage + (wave * 32 + i * C::ROWS_PER_DMA) * C::ROW_BYTES);
     }
     constexpr int RB = BN / (2 * WM);                         // B: 128 rows over all waves
 #pragma unroll
@@ -49,11 +50,7 @@ __device__ __forceinline__ void nt_stage_load(const bf16* __restrict__ A, int64_
         const int c = cp ^ C::swz(r);
         int64_t gn = n0 + r;
         gn = gn < N ? gn : N - 1;
-#ifdef NT_DBG_W_BLOCKED      // timing experiment: B read as if stored K-blocked [K/BKT][N][BKT] (every piece 1 KB contiguous)
-        const bf16* bsrc = B + (k0 / BKT) * N * BKT + gn * BKT + c * 8;
-#else
         const bf16* bsrc = B + gn * ldb + k0 + c * 8;
-#endif
         if constexpr (ASM_DMA) glds16_asm(bsrc, stage + C::A_BYTES + (wave * RB + i * C::ROWS_PER_DMA) * C::ROW_BYTES);
         else glds16(bsrc, stage + C::A_BYTES + (wave * RB + i * C::ROWS_PER_DMA) * C::ROW_BYTES);
     }
