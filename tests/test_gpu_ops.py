@@ -267,6 +267,53 @@ def test_linear_residual_layernorm_fwd(vited, gpu, M, K):
     assert torch.equal(inplace, y)
 
 
+def test_slot_schedule_kernels_give_the_same_bits_on_every_launch(vited, gpu):
+    """Race screen for the kernels whose LDS buffers are recycled behind counted waits and raw barriers (gemm_row.hip, the wide
+    weight-gradient kernel): an LDS-DMA that lands late, or a buffer rewritten early, shows as a result that differs between
+    launches.  Full-chip shapes (two tiles per CU, both tile heights), every launch preceded by unrelated memory traffic that
+    shifts the timing, 25 launches each, every output bit-identical to the first launch and correct against fp64 samples."""
+    ops = vited.ops
+    N = 384
+    noise = torch.empty(64 << 20, device=gpu)
+    for M, K in ((65536, 1536), (66560, 384), (65 * 1024, 1152), (65536, 768)):
+        a = _rand((M, K), gpu, 11, 1.0, torch.bfloat16)
+        w = _rand((N, K), gpu, 12, K ** -0.5, torch.bfloat16)
+        bias, res = _rand((N,), gpu, 13, 0.5), _rand((M, N), gpu, 14, 2.0)
+        gamma, beta = 1.0 + _rand((N,), gpu, 15, 0.2), _rand((N,), gpu, 16, 0.2)
+        first = None
+        for it in range(25):
+            noise.fill_(float(it))
+            y, h, mean, rstd = ops.linear_residual_layernorm_fwd(a, w, bias, res, gamma, beta, 1e-6)
+            dx, dx_lp, dg, db = ops.linear_layernorm_bwd(a, w, res, gamma, mean, rstd, want_lp=True)
+            out = (y, h, mean, rstd, dx, dx_lp, dg, db)
+            if first is None:
+                first = [t.clone() for t in out]
+                rows = torch.tensor([0, 1, 127, 128, 143, 144, M // 2 + 5, M - 130, M - 1], device=gpu)
+                ref = res[rows].double() + a[rows].double() @ w.double().t() + bias.double()
+                torch.testing.assert_close(y[rows].double(), ref, rtol=1e-5, atol=2e-5 * K ** 0.5)
+            else:
+                for t, f in zip(out, first):
+                    assert torch.equal(t, f), (M, K, it)
+    # the batched weight-gradient launch of one encoder block at the bench batch
+    m = 65536
+    shapes = [(m, 1152, 384), (m, 384, 384), (m, 1536, 384), (m, 384, 1536)]
+    items = []
+    for i, (mm, n, k) in enumerate(shapes):
+        items.append((_rand((mm, n), gpu, 40 + i, 1.0, torch.bfloat16), _rand((mm, k), gpu, 50 + i, 1.0, torch.bfloat16),
+                      torch.empty(n, k, device=gpu), torch.empty(n, device=gpu)))
+    first = None
+    for it in range(25):
+        noise.fill_(float(it))
+        assert ops.linear_bwd_weight_batched(items, False)
+        if first is None:
+            first = [(dw.clone(), db.clone()) for _, _, dw, db in items]
+            dy, x, dw, db = items[1]
+            torch.testing.assert_close(dw.double(), dy.double().t() @ x.double(), rtol=2e-4, atol=1e-2)
+        else:
+            for (_, _, dw, db), (fw, fb) in zip(items, first):
+                assert torch.equal(dw, fw) and torch.equal(db, fb), it
+
+
 @pytest.mark.parametrize('M,K', [(64, 384), (80, 1536), (65 * 8, 1152), (1000, 768), (4096 + 33, 1536), (65 * 64, 384), (16384, 1152), (13, 64), (300, 192)])
 def test_linear_layernorm_bwd(vited, gpu, M, K):
     """dx = dx_in + LN'(dy Wt^T) with the column sums, one kernel, against fp64 autograd through LayerNorm on the same
