@@ -233,7 +233,9 @@ def test_gemm_bench_scale_tiles(vited, gpu, M, N, K):
 # ---------------------------------------------------------------------------------------------
 # row-complete Linear + LayerNorm kernels (gemm_row.hip)
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize('M,K', [(64, 384), (80, 1536), (65 * 8, 384), (1000, 1152), (4096 + 33, 768), (65 * 64, 1536), (16384, 384), (13, 64), (200, 192)])
+@pytest.mark.parametrize('M,K', [(64, 384), (80, 1536), (65 * 8, 384), (1000, 1152), (4096 + 33, 768), (65 * 64, 1536), (16384, 384), (13, 64), (200, 192),
+                                  # the 96-row tile (one round of 256 tiles) and the 160-row tile (one round where 128 / 144 rows need two)
+                                  (24001, 384), (39993, 1152)])
 def test_linear_residual_layernorm_fwd(vited, gpu, M, K):
     """y = residual + a W^T + b and h = LayerNorm(y) in one kernel against fp64 on the same bf16-rounded operands: ragged M
     (partial last tile, both tile heights: 64-row tiles and the 80-row tiles picked for 65-row batches), every K of the step."""
@@ -275,7 +277,7 @@ def test_slot_schedule_kernels_give_the_same_bits_on_every_launch(vited, gpu):
     ops = vited.ops
     N = 384
     noise = torch.empty(64 << 20, device=gpu)
-    for M, K in ((65536, 1536), (66560, 384), (65 * 1024, 1152), (65536, 768)):
+    for M, K in ((65536, 1536), (66560, 384), (65 * 1024, 1152), (65536, 768), (24576, 1536), (72 * 1025, 384)):
         a = _rand((M, K), gpu, 11, 1.0, torch.bfloat16)
         w = _rand((N, K), gpu, 12, K ** -0.5, torch.bfloat16)
         bias, res = _rand((N,), gpu, 13, 0.5), _rand((M, N), gpu, 14, 2.0)
@@ -314,7 +316,8 @@ def test_slot_schedule_kernels_give_the_same_bits_on_every_launch(vited, gpu):
                 assert torch.equal(dw, fw) and torch.equal(db, fb), it
 
 
-@pytest.mark.parametrize('M,K', [(64, 384), (80, 1536), (65 * 8, 1152), (1000, 768), (4096 + 33, 1536), (65 * 64, 384), (16384, 1152), (13, 64), (300, 192)])
+@pytest.mark.parametrize('M,K', [(64, 384), (80, 1536), (65 * 8, 1152), (1000, 768), (4096 + 33, 1536), (65 * 64, 384), (16384, 1152), (13, 64), (300, 192),
+                                  (24001, 768), (39993, 384)])
 def test_linear_layernorm_bwd(vited, gpu, M, K):
     """dx = dx_in + LN'(dy Wt^T) with the column sums, one kernel, against fp64 autograd through LayerNorm on the same
     bf16-rounded operands.  d(LayerNorm output) stays fp32 inside the kernel, so it is MORE accurate than the two-kernel form

@@ -25,8 +25,8 @@
 // traffic in full lines, row statistics by 5-step butterflies, the next row's operands in flight under the current row's
 // arithmetic.  dh never reaches HBM and is never rounded to bf16.
 //
-// BM = 128 (MT = 8) or 144 (MT = 9), chosen per M so that the tiles fill the chip's 256 CUs in the fewest rounds
-// (65,536 rows = 512 x 128: two full rounds; 66,560 rows = 463 x 144: two rounds, where 520 x 128 would need three).
+// BM = 96 / 128 / 144 / 160 (MT = 6 / 8 / 9 / 10), chosen per M so that the tiles fill the chip's 256 CUs with the smallest makespan
+// (row_mt below: 65,536 rows = 512 x 128; 66,560 = 463 x 144; 73,800 = 462 x 160; 24,576 = 256 x 96).
 #include <mutex>
 #include <type_traits>
 
@@ -56,17 +56,23 @@ struct RowArgs {
 };
 
 template <int MT> struct RowCfg {
-    static_assert(MT == 8 || MT == 9, "tile heights: 128 or 144 rows");
+    static_assert(MT == 6 || MT == 8 || MT == 9 || MT == 10, "tile heights: 96, 128, 144 or 160 rows");
     static constexpr int BM = 16 * MT;
-    static constexpr int A_BYTES = BM * 128;                             // one K = 64 tile of the A panel: 16 / 18 KB
+    static constexpr int A_BYTES = BM * 128;                             // one K = 64 tile of the A panel: 12 - 20 KB
     static constexpr int W_BYTES = ROW_N * 128;                          // ... of the whole W panel: 48 KB
     static constexpr int W_BASE = 3 * A_BYTES;
-    static constexpr int LDS_BYTES = 3 * A_BYTES + 2 * W_BYTES;          // 147,456 / 153,600
-    static constexpr int P0 = (MT + 1) / 2;                              // row tiles of a K-tile's first phase: 4 / 5
-    static constexpr int PASS_SUB = MT == 8 ? 4 : 3;                     // 16-row sub-tiles per epilogue pass
-    static constexpr int PASS_ROWS = 16 * PASS_SUB;                      // 64 / 48
+    static constexpr int LDS_BYTES = 3 * A_BYTES + 2 * W_BYTES;          // 135,168 ... 159,744
+    static constexpr int P0 = (MT + 1) / 2;                              // row tiles of a K-tile's first phase
+    static constexpr int A_PIECES = 2 * MT;                              // 8-row LDS-DMA pieces of an A tile: group 0's wave u takes u, u + 4, ...
+    static constexpr int A_J = (A_PIECES + 3) / 4;                       // ... at most this many
+    static constexpr int PASS_SUB = MT == 8 ? 4 : MT == 10 ? 5 : 3;      // 16-row sub-tiles per epilogue pass
+    static constexpr int PASS_ROWS = 16 * PASS_SUB;                      // 48 / 64 / 80
     static constexpr int NPASS = MT / PASS_SUB;                          // 2 / 3
-    static constexpr int ROWS_PER_HALF = PASS_ROWS / 16;                 // rows of a pass per half-wave (16 half-waves): 4 / 3
+    static constexpr int ROWS_PER_HALF = PASS_ROWS / 16;                 // rows of a pass per half-wave (16 half-waves)
+    // all of a pass's row operands in flight at once where the registers allow it (the backward row carries 26 values per lane)
+    static constexpr bool EPI_ALL_ROWS = MT <= 9;
+    static_assert(MT % PASS_SUB == 0, "passes cover the tile");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
     static_assert(LDS_BYTES >= PASS_ROWS * ROW_LD * 4, "epilogue scratch must fit the staging buffers");
     static_assert(LDS_BYTES >= 16 * 2 * ROW_N * 4, "column-partial combine must fit the staging buffers");
 };
@@ -123,26 +129,20 @@ gemm_row_kernel(const RowArgs a) {
     const int nt = a.K / 64;
     const int r8 = lane >> 3, c8 = lane & 7;
     const int cs_even = (c8 ^ (r8 >> 1)) * 8, cs_odd = (c8 ^ (r8 >> 1) ^ 4) * 8;
-    // group 0 stages A: wave u pieces 4 u .. 4 u + 3 (+ piece 16 + u for u < 2 when MT = 9)
-    const bf16* pa[4];
-    const bf16* pax = nullptr;
+    // group 0 stages A: wave u takes pieces u, u + 4, u + 8, ... of the tile's 2 MT (piece parity = u & 1); W parts likewise
+    const int cs_u = (u & 1) ? cs_odd : cs_even;
+    const int a_per = (R::A_PIECES - u + 3) / 4;          // 3, 4 or 5 pieces for this wave (wave-uniform)
+    const bf16* pa[R::A_J];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        int64_t ar = m0 + 32 * u + 8 * j + r8;
+    for (int j = 0; j < R::A_J; ++j) {
+        int64_t ar = m0 + 8 * (4 * j + u) + r8;
 #ifdef ROW_DBG_A_RESIDENT                    // timing experiment: every workgroup stages the FIRST tile's rows (A served by L2, not HBM)
         ar -= m0;
 #endif
         ar = ar < a.M ? ar : a.M - 1;        // rows past M are staged from the last row and never stored
-        pa[j] = a.A + ar * a.lda + ((j & 1) ? cs_odd : cs_even);
+        pa[j] = a.A + ar * a.lda + cs_u;
     }
-    const bool a_extra = MT == 9 && grp == 0 && u < 2;
-    if (MT == 9) {
-        int64_t ar = m0 + 128 + 8 * u + r8;
-        ar = ar < a.M ? ar : a.M - 1;
-        pax = a.A + ar * a.lda + ((u & 1) ? cs_odd : cs_even);
-    }
-    const bf16* pw_even = a.W + (int64_t)(32 * u + r8) * a.ldw + cs_even;
-    const bf16* pw_odd = a.W + (int64_t)(32 * u + r8) * a.ldw + cs_odd;
+    const bf16* pw = a.W + (int64_t)(8 * u + r8) * a.ldw + cs_u;
     auto issue_a = [&](int t) {
 #ifdef ROW_DBG_NO_DMA
         return;
@@ -153,18 +153,18 @@ gemm_row_kernel(const RowArgs a) {
         const int seg = k0 / a.seg_k;                                         // scalar: which [M, seg_k] tensor this K-tile reads
         const int64_t ka = (int64_t)seg * a.seg_stride + (k0 - seg * a.seg_k);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) glds16_asm(pa[j] + ka, dst + (4 * u + j) * 1024);
-        if (a_extra) glds16_asm(pax + ka, dst + (16 + u) * 1024);
+        for (int j = 0; j < R::A_J; ++j)
+            if (4 * j + 3 < R::A_PIECES || j < a_per) glds16_asm(pa[j] + ka, dst + (4 * j + u) * 1024);
     };
     auto issue_w = [&](int t, int part) {
 #ifdef ROW_DBG_NO_DMA
         return;
 #endif
         if (t >= nt) return;
-        char* dst = smem + R::W_BASE + (t & 1) * R::W_BYTES + (16 * part + 4 * u) * 1024;
+        char* dst = smem + R::W_BASE + (t & 1) * R::W_BYTES + (16 * part + u) * 1024;
         const int64_t off = (int64_t)(128 * part) * a.ldw + t * 64;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) glds16_asm(((j & 1) ? pw_odd : pw_even) + off + (int64_t)(8 * j) * a.ldw, dst + j * 1024);
+        for (int j = 0; j < 4; ++j) glds16_asm(pw + off + (int64_t)(32 * j) * a.ldw, dst + 4 * j * 1024);
     };
     // fragments: row (16 i + fr) of A / row (48 wave + 16 j + fr) of W, k-half kk -> 16-byte chunk 4 kk + fq; swz(row) = (fr >> 1) & 7
     const int fr = lane & 15, fq = lane >> 4;
@@ -219,7 +219,8 @@ gemm_row_kernel(const RowArgs a) {
     auto certify_barrier = [&](bool younger) {
         __builtin_amdgcn_sched_barrier(0);
         if (!younger) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        else if (a_extra) asm volatile("s_waitcnt vmcnt(5)\n\ts_barrier" ::: "memory");
+        else if (grp == 0 && a_per == 5) asm volatile("s_waitcnt vmcnt(5)\n\ts_barrier" ::: "memory");
+        else if (grp == 0 && a_per == 3) asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -393,23 +394,17 @@ gemm_row_kernel(const RowArgs a) {
 #pragma unroll
     for (int p = 0; p < R::NPASS; ++p) {
         const int64_t mp = m0 + p * R::PASS_ROWS;
-#ifndef ROW_EPI_ONE_AHEAD
-        // ALL of this half-wave's rows of the pass are requested before the dump and its two barriers: a half-wave is one of only
-        // 16 per CU, and with one row (1.5 - 3 KB) in flight each the epilogue ran at the latency-bound ~5 TB/s, not the HBM rate
-        RowFwdIn fin[R::ROWS_PER_HALF];
-        RowBwdIn bin[R::ROWS_PER_HALF];
+        // ALL of this half-wave's rows of the pass are requested before the dump and its two barriers where the registers allow
+        // (a half-wave is one of only 16 per CU: with one row - 1.5 to 3 KB - in flight each the epilogue was 2-3 % slower);
+        // the 160-row tile keeps one row ahead
+        constexpr int AHEAD = R::EPI_ALL_ROWS ? R::ROWS_PER_HALF : 1;
+        RowFwdIn fin[AHEAD + (R::EPI_ALL_ROWS ? 0 : 1)];
+        RowBwdIn bin[AHEAD + (R::EPI_ALL_ROWS ? 0 : 1)];
 #pragma unroll
-        for (int k = 0; k < R::ROWS_PER_HALF; ++k) {
+        for (int k = 0; k < AHEAD; ++k) {
             if (MODE == ROW_MODE_FWD) load_fwd(fin[k], mp + hw + 16 * k);
             else load_bwd(bin[k], mp + hw + 16 * k);
         }
-#else
-        RowFwdIn fcur, fnxt;
-        RowBwdIn bcur, bnxt;
-        // the first row's operands travel under the dump and its two barriers
-        if (MODE == ROW_MODE_FWD) load_fwd(fcur, mp + hw);
-        else load_bwd(bcur, mp + hw);
-#endif
         __syncthreads();       // every wave is done with the LDS (main loop's last stage / the previous pass's rows)
 #pragma unroll
         for (int ii = 0; ii < R::PASS_SUB; ++ii) {
@@ -421,21 +416,19 @@ gemm_row_kernel(const RowArgs a) {
 #pragma unroll
         for (int k = 0; k < R::ROWS_PER_HALF; ++k) {
             const int r = hw + 16 * k;
-#ifndef ROW_EPI_ONE_AHEAD
-            if (MODE == ROW_MODE_FWD) row_fwd(fin[k], r, mp + r);
-            else row_bwd(bin[k], r, mp + r);
-#else
-            const bool more = k + 1 < R::ROWS_PER_HALF;
-            if (MODE == ROW_MODE_FWD) {
-                if (more) load_fwd(fnxt, mp + r + 16);
-                row_fwd(fcur, r, mp + r);
-                if (more) fcur = fnxt;
+            if constexpr (R::EPI_ALL_ROWS) {
+                if (MODE == ROW_MODE_FWD) row_fwd(fin[k], r, mp + r);
+                else row_bwd(bin[k], r, mp + r);
             } else {
-                if (more) load_bwd(bnxt, mp + r + 16);
-                row_bwd(bcur, r, mp + r);
-                if (more) bcur = bnxt;
+                const bool more = k + 1 < R::ROWS_PER_HALF;
+                if (MODE == ROW_MODE_FWD) {
+                    if (more) load_fwd(fin[(k + 1) & 1], mp + r + 16);
+                    row_fwd(fin[k & 1], r, mp + r);
+                } else {
+                    if (more) load_bwd(bin[(k + 1) & 1], mp + r + 16);
+                    row_bwd(bin[k & 1], r, mp + r);
+                }
             }
-#endif
         }
     }
 
@@ -462,9 +455,20 @@ gemm_row_kernel(const RowArgs a) {
 
 // ------------------------------------------------------------------------------------------------
 static inline int row_mt(int64_t M) {
-    // rounds of 256 workgroups (one per CU) x rows per tile: the smaller makespan wins
-    const int64_t c8 = ceil_div64(ceil_div64(M, 128), 256) * 128, c9 = ceil_div64(ceil_div64(M, 144), 256) * 144;
-    return c9 < c8 ? 9 : 8;
+    // rounds of 256 workgroups (one per CU) x rows per tile: the smallest makespan wins, the taller tile on a tie (the W panel
+    // is staged once per tile).  65,536 rows = 512 x 128 (two rounds); 66,560 = 463 x 144 (two rounds, where 520 x 128 needs three);
+    // 73,800 (config H's decoder, 72 pairs) = 462 x 160 (two rounds of 160 rows against three of 128); 24,576 = 256 x 96 (one).
+    static const int heights[] = {10, 9, 8, 6};
+    int best = 8;
+    int64_t cost = -1;
+    for (int mt : heights) {
+        const int64_t c = ceil_div64(ceil_div64(M, 16 * mt), 256) * mt;
+        if (cost < 0 || c < cost) {
+            cost = c;
+            best = mt;
+        }
+    }
+    return best;
 }
 
 static inline int64_t row_tiles(int64_t M) { return ceil_div64(M, 16 * row_mt(M)); }
@@ -487,7 +491,12 @@ static int row_launch_mt(const RowArgs& a, unsigned tiles, hipStream_t s) {
 template <int MODE>
 static int row_launch(const RowArgs& a, hipStream_t s) {
     const unsigned tiles = (unsigned)row_tiles(a.M);
-    return row_mt(a.M) == 9 ? row_launch_mt<MODE, 9>(a, tiles, s) : row_launch_mt<MODE, 8>(a, tiles, s);
+    switch (row_mt(a.M)) {
+        case 6: return row_launch_mt<MODE, 6>(a, tiles, s);
+        case 9: return row_launch_mt<MODE, 9>(a, tiles, s);
+        case 10: return row_launch_mt<MODE, 10>(a, tiles, s);
+        default: return row_launch_mt<MODE, 8>(a, tiles, s);
+    }
 }
 
 static inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
