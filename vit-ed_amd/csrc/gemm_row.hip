@@ -10,20 +10,21 @@
 // so every LayerNorm was its own streaming pass over the fp32 residual stream (196 launches, 4.9 ms of a 30 ms step, round 2).
 // Here one workgroup owns BM complete rows.
 //
-// Main loop = the pipeline of the wide weight-gradient kernel (gemm_tn_wide_kernel): ONE 8-wave workgroup per CU, a 4-slot LDS
-// ring of K = 32 stages (A panel BM x 64 B + the whole W panel 384 x 64 B = 32-33 KB), three stages in flight across a raw
-// s_barrier with counted vmcnt (LDS-DMA from inline asm), the fragments of step t + 1 read under the MFMAs of step t, and the two
-// waves of a SIMD (w, w + 4) taking "issue the next stage's DMA" and "the step's MFMAs" in opposite order.  The W panel is staged
-// once per BM = 128 / 144 rows: 1/96 B per FLOP through the L2 -> LDS path against 1/64 for the 128 x 128 tile.
-// (A first form with 64 / 80-row tiles, two 4-wave workgroups per CU and a two-stage image staged 1/56 B per FLOP with one stage
-// in flight: 500 TF/s in the K loop - slower than the two kernels it replaced for K >= 768.  profiles/README.md, round 3.)
+// ONE 8-wave workgroup per CU; the W panel is staged once per BM rows (1/96 B per FLOP at BM = 128 against 1/64 for a 128 x 128 tile).
+// Main loop (third form; the schedule is described where it is written, below): K = 64 tiles staged as full 128-byte lines into
+// three A buffers + two W buffers, MFMA clusters and load slots separated by raw s_barriers with the two wave groups one slot
+// apart, counted vmcnt.  History, all measured at K = 1536, M = 65,536 (profiles/row_probe.py):
+//   1. 64 / 80-row tiles, two 4-wave workgroups per CU, a two-stage image: 500 TF/s in the K loop - slower than the two kernels
+//      it replaced for K >= 768;
+//   2. 128 / 144-row tiles, a 4-slot ring of K = 32 stages (16 rows x 64 B LDS-DMA pieces), one barrier per step, fragment
+//      double buffer, waves w / w + 4 in opposite DMA / MFMA order: 820 TF/s in the K loop, kernel 138 us;
+//   3. this one: 1.0 - 1.1 PF/s in the K loop, kernel 117 - 125 us.
 // Waves sit side by side: wave w owns all BM rows x columns 48 w .. 48 w + 47 (MT x 3 accumulators of v_mfma_f32_16x16x32_bf16).
 //
 // The product is issued transposed (W fragment as the A operand): a lane then holds 4 CONSECUTIVE columns of one row and the
-// tile goes to an fp32 LDS scratch (64 or 48 rows x 388 floats per pass, reusing the ring) as 16-byte stores; from there the
+// tile goes to an fp32 LDS scratch (48 - 80 rows x 388 floats per pass, reusing the staging buffers) as 16-byte stores; from there the
 // epilogue is the LayerNorm kernels' own row loop (layernorm.hip): a 32-lane half-wave owns a row, 3 float4 per lane, all global
-// traffic in full lines, row statistics by 5-step butterflies, the next row's operands in flight under the current row's
-// arithmetic.  dh never reaches HBM and is never rounded to bf16.
+// traffic in full lines, row statistics by 5-step butterflies, the pass's row operands requested before the dump.  dh never reaches HBM and is never rounded to bf16.
 //
 // BM = 96 / 128 / 144 / 160 (MT = 6 / 8 / 9 / 10), chosen per M so that the tiles fill the chip's 256 CUs with the smallest makespan
 // (row_mt below: 65,536 rows = 512 x 128; 66,560 = 463 x 144; 73,800 = 462 x 160; 24,576 = 256 x 96).
