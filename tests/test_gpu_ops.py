@@ -476,7 +476,9 @@ def _sdpa_ref(q, k, v, heads, scale):
 @pytest.mark.parametrize('B,H,Nq,Nk,hd', [(3, 12, 64, 64, 32), (3, 12, 65, 65, 32), (2, 12, 65, 64, 32), (2, 6, 257, 256, 64),
                                           (1, 6, 1025, 1024, 64), (2, 1, 5, 4, 32), (1, 2, 1, 1, 64), (2, 3, 200, 130, 32),
                                           (1, 6, 1024, 1024, 64), (1, 6, 1025, 1025, 64), (2, 2, 65, 65, 64), (1, 4, 129, 81, 32),
-                                          (300, 12, 65, 64, 32), (257, 6, 64, 64, 32), (129, 5, 65, 65, 32)])
+                                          (300, 12, 65, 64, 32), (257, 6, 64, 64, 32), (129, 5, 65, 65, 32),
+                                          # 65 = 4 x 16 + 1: the one-extra-row path of the backward (query, key, both; cls-only queries)
+                                          (7, 12, 64, 65, 32), (5, 12, 1, 65, 32), (9, 7, 16, 65, 32), (1030, 12, 65, 65, 32)])
 def test_attention_fwd_bwd(vited, gpu, dtype, B, H, Nq, Nk, hd):
     ops = vited.ops
     D = H * hd
