@@ -207,6 +207,7 @@ bool gemm_nt_mfma_supported(const void* A, int64_t lda, const void* B, int64_t l
     if ((epilogue == VITED_EPI_MUL_GELU_GRAD || epilogue == VITED_EPI_MUL) && !al16(ep.aux)) return false;
     if (epilogue == VITED_EPI_RESIDUAL && !al16(ep.residual)) return false;
     if (ceil_div64(M, 128) * ceil_div64(N, BN) > (1 << 30)) return false;
+    if (M >= ((int64_t)1 << 31) || ep.rows_per_batch >= ((int64_t)1 << 31)) return false;   // the row remap divides in 32 bits
     return true;
 }
 

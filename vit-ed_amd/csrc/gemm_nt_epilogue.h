@@ -43,7 +43,9 @@ __device__ __forceinline__ void remap_rows(const EpiParams& p, int64_t m, int64_
     orow = m;
     rrow = m;
     if (p.rows_per_batch > 0) {
-        const int64_t b = m / p.rows_per_batch, r = m - b * p.rows_per_batch + p.row_offset;
+        // 32-bit division (gemm_nt_mfma_supported bounds M): the 64-bit one is a ~100-instruction routine, issued 32 times per
+        // lane and tile by the patch-embedding GEMM's epilogue (K = 192: three K-steps of MFMA work per tile)
+        const int64_t b = (uint32_t)m / (uint32_t)p.rows_per_batch, r = m - b * p.rows_per_batch + p.row_offset;
         orow = b * p.out_rows_per_batch + r;
         rrow = p.residual_bcast ? r : orow;
     }
