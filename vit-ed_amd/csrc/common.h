@@ -76,6 +76,21 @@ __device__ __forceinline__ float gelu_grad_fast(float x) {
     return fmaf(x * 0.39894228040143268f, e, cdf);
 }
 
+// Sum over the 32 lanes of a half-wave (the LayerNorm kernels' row owner); every lane gets the sum.  Four DPP row rotations
+// (vector instructions, no LDS) sum the two 16-lane rows, ONE ds_swizzle adds the other row: the 5-step __shfl_xor butterfly it
+// replaces compiles to five DEPENDENT ds_bpermute_b32 (an LDS round trip each), and a LayerNorm row needs two of them in series.
+template <int N> __device__ __forceinline__ float dpp_row_ror(float v) {   // lane i of a 16-lane row takes lane (i + N) % 16's value
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float half_wave_sum(float v) {
+    v += dpp_row_ror<8>(v);
+    v += dpp_row_ror<4>(v);
+    v += dpp_row_ror<2>(v);
+    v += dpp_row_ror<1>(v);
+    // bit-mask swizzle: and 0x1f, or 0, xor 0x10 -> lane i reads lane i ^ 16 of its 32-lane group
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));
+}
+
 static inline int vited_check_launch() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? VITED_OK : VITED_ERR_LAUNCH;

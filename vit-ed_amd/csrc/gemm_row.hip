@@ -24,7 +24,7 @@
 // The product is issued transposed (W fragment as the A operand): a lane then holds 4 CONSECUTIVE columns of one row and the
 // tile goes to an fp32 LDS scratch (48 - 80 rows x 388 floats per pass, reusing the staging buffers) as 16-byte stores; from there the
 // epilogue is the LayerNorm kernels' own row loop (layernorm.hip): a 32-lane half-wave owns a row, 3 float4 per lane, all global
-// traffic in full lines, row statistics by 5-step butterflies, the pass's row operands requested before the dump.  dh never reaches HBM and is never rounded to bf16.
+// traffic in full lines, row statistics by DPP row sums + one swizzle, the pass's row operands requested before the dump.  dh never reaches HBM and is never rounded to bf16.
 //
 // BM = 96 / 128 / 144 / 160 (MT = 6 / 8 / 9 / 10), chosen per M so that the tiles fill the chip's 256 CUs with the smallest makespan
 // (row_mt below: 65,536 rows = 512 x 128; 66,560 = 463 x 144; 73,800 = 462 x 160; 24,576 = 256 x 96).
@@ -78,11 +78,7 @@ template <int MT> struct RowCfg {
     static_assert(LDS_BYTES >= 16 * 2 * ROW_N * 4, "column-partial combine must fit the staging buffers");
 };
 
-__device__ __forceinline__ float row_half_sum(float v) {   // over the 32 lanes of a half-wave
-#pragma unroll
-    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
+__device__ __forceinline__ float row_half_sum(float v) { return half_wave_sum(v); }   // over the 32 lanes of a half-wave (common.h)
 
 // outputs are written once and read by a later kernel: streaming stores (see gemm_nt_epilogue.h for the measurements)
 #define ROW_STORE(ptr, val) __builtin_nontemporal_store(val, ptr)

@@ -1,6 +1,6 @@
 // LayerNorm forward/backward for the ViT-ED residual stream (fp32 in, activation dtype out).
 // HBM-bound streaming kernels: a 32-lane half-wave owns one token row, every lane moves 16-byte
-// vectors (dim 384 = 3 float4 per lane), row statistics are 5-step butterflies inside the half-wave,
+// vectors (dim 384 = 3 float4 per lane), row statistics are DPP row sums + one swizzle inside the half-wave,
 // no LDS in the forward.  The backward also produces the gamma/beta column sums: per-lane register
 // partials over the rows a lane sees -> one LDS combine per workgroup -> [blocks][2][dim] partial
 // slabs -> a small deterministic finishing pass (no atomics).
@@ -8,11 +8,7 @@
 
 #define LN_MAX_VPL 8  // float4 vectors per lane: dim <= 32 * 4 * 8 = 1024
 
-__device__ __forceinline__ float half_sum(float v) {  // over the 32 lanes of a half-wave
-#pragma unroll
-    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
+__device__ __forceinline__ float half_sum(float v) { return half_wave_sum(v); }   // over the 32 lanes of a half-wave (common.h)
 
 template <typename T> struct Vec4;
 template <> struct Vec4<float> {
