@@ -163,7 +163,7 @@ int vited_linear_bwd_weight(const void* dY, int64_t lddy, const void* X, int64_t
                             int64_t workspace_bytes, void* stream);
 
 /* Several weight gradients in ONE launch: the dW / dbias of every Linear of one transformer block (Block / CrossBlock backward,
- * vision_transformer.py:124-127, 268-272), queued by the caller and flushed together.  Arrays have `count` (<= 8) entries, all
+ * vision_transformer.py:124-127, 268-272), queued by the caller and flushed together.  Arrays have `count` (<= 40) entries, all
  * host memory; entry i is the product of vited_linear_bwd_weight with the same meanings (dbias[i] may be null).  Sharing the
  * chip's workgroup slots between the products cuts the number of row splits - and the fp32 partial slabs - several-fold.
  * bf16 only, every K a multiple of 384 and every M >= 4096 (vited_linear_bwd_weight_batched_supported); otherwise the caller

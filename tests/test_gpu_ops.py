@@ -447,7 +447,7 @@ def test_linear_bwd_weight_batched(vited, gpu, accumulate):
     assert not ops.linear_bwd_weight_batched([items[0], small], accumulate)
     odd = (_rand((m2, 384), gpu, 3, 1.0, torch.bfloat16), _rand((m2, 192), gpu, 4, 1.0, torch.bfloat16), torch.zeros(384, 192, device=gpu), None)
     assert not ops.linear_bwd_weight_batched([items[0], odd], accumulate)
-    assert not ops.linear_bwd_weight_batched(items + items[:2], accumulate)      # more than 8 products
+    assert not ops.linear_bwd_weight_batched(items * 6, accumulate)               # more than 40 products
 
 
 def test_linear_bwd_weight_wide_strided_operands(vited, gpu):

@@ -492,7 +492,7 @@ int sum_rows_f32_single_pass(const float* in, int64_t in_ld, float* out, int64_t
 // The slabs of a batched weight-gradient launch (gemm_tn_batch): one split's block = the products' [N, K] slabs back to back
 // (slab_stride floats), bias sums likewise (bias_stride floats).  One launch sums every product's slabs onto ITS dW / dbias:
 // a thread owns 4 consecutive floats of the concatenated width (every product's width is a multiple of 4).
-#define SB_MAX 8
+#define SB_MAX 40
 struct SumBatch {
     float* out[2 * SB_MAX];        // dW of product i, then dbias of product i (null = none)
     int64_t start[2 * SB_MAX + 1]; // first float of each section in the concatenated space [slabs | bias slabs]

@@ -124,8 +124,8 @@ extern "C" int vited_linear_bwd_weight_batched(int count, const void* const* dY,
     if (workspace_bytes < vited_linear_bwd_weight_batched_workspace_bytes(count, M, N, K)) return VITED_ERR_WORKSPACE;
     int64_t splits, ws, bs;
     gemm_tn_batch_layout(count, M, N, K, &splits, &ws, &bs);
-    int has_bias[8];
-    int64_t widths[8], nbias[8];
+    int has_bias[40];
+    int64_t widths[40], nbias[40];
     for (int i = 0; i < count; ++i) {
         if (!dY[i] || !X[i] || !dW[i] || lddy[i] < N[i] || ldx[i] < K[i]) return VITED_ERR_BAD_ARG;
         has_bias[i] = dbias[i] != nullptr;

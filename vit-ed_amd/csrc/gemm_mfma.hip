@@ -529,7 +529,7 @@ __device__ __forceinline__ void tw_read_frags(TwFrags& f, const char* st, const 
 // functions.py and flushed at the end of the block's backward): the chip's 256 workgroup slots are then shared by ~36-48 output
 // tiles instead of 3-12, so each product is split over 5-7 row ranges instead of 21-85 and writes that many fewer fp32 slabs
 // (round 2: 9 GB of slab traffic per step, as much as the operands for the N = K = 384 products).
-#define TW_MAX_PROBLEMS 8
+#define TW_MAX_PROBLEMS 40      // 40 x 88 B of descriptors ride in the kernel arguments (4 KB limit)
 struct TwProblem {
     const bf16* dY;
     const bf16* X;

@@ -81,6 +81,7 @@ class Runtime:
         self.fused_mlp = os.environ.get('VITED_FUSED_MLP', '1') != '0'   # vited_mlp_fwd on the no-grad paths
         self.fused_ln = os.environ.get('VITED_FUSED_LN', '1') != '0'     # LayerNorm inside the neighbouring Linear's kernel (gemm_row.hip)
         self.batch_dw = os.environ.get('VITED_BATCH_DW', '1') != '0'     # a block's weight gradients in one launch (vited_linear_bwd_weight_batched)
+        self.group_dw = os.environ.get('VITED_GROUP_DW', '1') != '0'     # ... and several blocks' together while they fit one round of workgroups
         self.dw_queue = None        # inside a block's backward: [(dy, x, dW target, dbias target | None, accumulate)]
         self.ln_queue = None        # inside a Function's backward: deferred LayerNorm column sums (ops.layernorm_bwd_finish)
         self.fold_context = os.environ.get('VITED_FOLD_CONTEXT', '1') != '0'   # norm_context + kv of all decoder blocks as one GEMM
@@ -224,21 +225,49 @@ def _weight_grads(rt, dy, x_saved, w, b):
 
 class _DwBatch:
     """``with _DwBatch(rt):`` around one block's backward: the weight-gradient products issued inside are collected and
-    launched together on exit (vited_linear_bwd_weight_batched) - they only read tensors the block's backward already produced,
-    and nothing inside the block consumes a weight gradient."""
+    launched together (vited_linear_bwd_weight_batched) - they only read tensors the block's backward already produced, and
+    nothing inside a backward pass consumes a weight gradient.
 
-    def __init__(self, rt):
-        self.rt = rt
+    ``with _DwBatch(rt, blocks=True) as g:`` around a LOOP over blocks, ``with g.block():`` around each: the products of several
+    blocks go out together, flushed when another block of the same size would no longer fit one round of 256 workgroups
+    (an encoder block of the embed-384 models is 36 output tiles of 128 x 384: seven blocks = 252 tiles = ONE row range per
+    product - no split-M slabs to write and sum - where one block alone is cut into 7 row ranges)."""
+
+    ROUND = 256
+
+    def __init__(self, rt, blocks=False):
+        self.rt, self.blocks = rt, blocks and rt.group_dw
 
     def __enter__(self):
         self.outer = self.rt.dw_queue
         self.rt.dw_queue = [] if (self.rt.batch_dw and not self.rt.exact) else None
+        self.mark = 0
         return self
 
-    def __exit__(self, exc_type, *exc):
-        q, self.rt.dw_queue = self.rt.dw_queue, self.outer
-        if exc_type is not None or not q:
-            return False
+    def block(self):
+        return _DwBlock(self)
+
+    @staticmethod
+    def _tiles(items):
+        return sum(-(-dy.shape[1] // 128) * (x.shape[1] // 384) for dy, x, _dw, _db, _a in items)
+
+    def _end_of_block(self):
+        q = self.rt.dw_queue
+        if q is None:
+            return
+        if not self.blocks:
+            self.flush()
+            return
+        this, count = self._tiles(q[self.mark:]), len(q) - self.mark      # the block that just ended: the next one is taken to be alike
+        self.mark = len(q)
+        if self._tiles(q) + this > self.ROUND or len(q) + count > ops.MAX_BATCHED_WEIGHT_GRADS:
+            self.flush()
+
+    def flush(self):
+        q = self.rt.dw_queue
+        if not q:
+            return
+        self.rt.dw_queue, self.mark = [], 0
         for acc in (True, False):
             group = [(dy, x, dw, db) for dy, x, dw, db, a in q if a == acc]
             for i in range(0, len(group), ops.MAX_BATCHED_WEIGHT_GRADS):
@@ -248,6 +277,24 @@ class _DwBatch:
                 for dy, x, dw, db in part:
                     ops.linear_bwd_weight(dy, x, want_bias=db is not None, dw_out=dw, db_out=db) if acc else \
                         _overwrite_weight_grad(dy, x, dw, db)
+
+    def __exit__(self, exc_type, *exc):
+        if exc_type is None:
+            self.flush()
+        self.rt.dw_queue = self.outer
+        return False
+
+
+class _DwBlock:
+    def __init__(self, group):
+        self.group = group
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, exc_type, *exc):
+        if exc_type is None:
+            self.group._end_of_block()
         return False
 
 
@@ -491,19 +538,20 @@ class EncoderFn(torch.autograd.Function):
         dx_lp = _lp(rt, dx)
         grads = [None] * len(params)
         rt.ln_queue = [] if not rt.exact else None
-        for i in reversed(range(rt.depth)):
-            g1, b1, wqkv, bqkv, wproj, bproj, g2, b2, w1, bb1, w2, bb2 = params[3 + i * nb: 3 + (i + 1) * nb]
-            x, sa, xa, sm = ctx.tape[i]
-            ctx.tape[i] = None
-            with _BlockSpan(rt, 'enc', i, 'bwd'), _DwBatch(rt):
-                dx, dx_lp, (dg2, db2, dw1, dbb1, dw2, dbb2) = _mlp_bwd(rt, dx, dx_lp, xa, g2, b2, w1, bb1, w2, bb2, sm)
-                dx, dx_lp, (dg1, db1, dwq, dbq, dwp, dbp) = _attn_branch_bwd(rt, dx, dx_lp, x, g1, b1, wqkv, bqkv, wproj, bproj, sa, batch, n,
-                                                                             key=('blocks', i, 'attn'))
-            if rt.tap is not None:
-                rt.tap[f'enc.dx.{i}'] = dx.clone()      # gradient w.r.t. the INPUT of encoder block i
-            base = 3 + i * nb
-            blk = [dg1, db1, dwq, dbq, dwp, dbp, dg2, db2, dw1, dbb1, dw2, dbb2]
-            grads[base: base + nb] = blk
+        with _DwBatch(rt, blocks=True) as dwg:
+            for i in reversed(range(rt.depth)):
+                g1, b1, wqkv, bqkv, wproj, bproj, g2, b2, w1, bb1, w2, bb2 = params[3 + i * nb: 3 + (i + 1) * nb]
+                x, sa, xa, sm = ctx.tape[i]
+                ctx.tape[i] = None
+                with _BlockSpan(rt, 'enc', i, 'bwd'), dwg.block():
+                    dx, dx_lp, (dg2, db2, dw1, dbb1, dw2, dbb2) = _mlp_bwd(rt, dx, dx_lp, xa, g2, b2, w1, bb1, w2, bb2, sm)
+                    dx, dx_lp, (dg1, db1, dwq, dbq, dwp, dbp) = _attn_branch_bwd(rt, dx, dx_lp, x, g1, b1, wqkv, bqkv, wproj, bproj, sa, batch, n,
+                                                                                 key=('blocks', i, 'attn'))
+                if rt.tap is not None:
+                    rt.tap[f'enc.dx.{i}'] = dx.clone()      # gradient w.r.t. the INPUT of encoder block i
+                base = 3 + i * nb
+                blk = [dg1, db1, dwq, dbq, dwp, dbp, dg2, db2, dw1, dbb1, dw2, dbb2]
+                grads[base: base + nb] = blk
         if rt.ln_queue is not None:
             ops.layernorm_bwd_finish(rt.ln_queue)       # the encoder's 2 x depth LayerNorm column sums: one launch per 16
             rt.ln_queue = None
@@ -833,20 +881,21 @@ class DecoderFn(torch.autograd.Function):
         if ctx.fold is not None:
             dkv_all = torch.empty_like(ctx.fold[0])
             dkv_all3 = dkv_all
-        for i in reversed(range(rt.c_depth)):
-            P = params[ns + i * nb: ns + (i + 1) * nb]
-            entry = ctx.tape[i]
-            ctx.tape[i] = None
-            with _DwBatch(rt):
-                dx, dx_lp, dctx, blk = _dec_block_bwd(rt, dx, dx_lp, ctx.ctxf, dctx, P, entry, batch, n,
-                                                      ctx.cls_tail and i == rt.c_depth - 1, i,
-                                                      dkv3=dkv_all3[i].view(batch, rt.n1, 2 * d) if dkv_all3 is not None else None)
-            if rt.tap is not None:
-                rt.tap[f'dec.dx.{i}'] = dx.clone()      # gradient w.r.t. the INPUT of decoder block i
-                if dctx is not None:
-                    rt.tap[f'dec.dctx.{i}'] = dctx.clone()  # running d(features) after blocks c_depth-1 .. i
-            base = ns + i * nb
-            grads[base: base + nb] = blk
+        with _DwBatch(rt, blocks=True) as dwg:
+            for i in reversed(range(rt.c_depth)):
+                P = params[ns + i * nb: ns + (i + 1) * nb]
+                entry = ctx.tape[i]
+                ctx.tape[i] = None
+                with dwg.block():
+                    dx, dx_lp, dctx, blk = _dec_block_bwd(rt, dx, dx_lp, ctx.ctxf, dctx, P, entry, batch, n,
+                                                          ctx.cls_tail and i == rt.c_depth - 1, i,
+                                                          dkv3=dkv_all3[i].view(batch, rt.n1, 2 * d) if dkv_all3 is not None else None)
+                if rt.tap is not None:
+                    rt.tap[f'dec.dx.{i}'] = dx.clone()      # gradient w.r.t. the INPUT of decoder block i
+                    if dctx is not None:
+                        rt.tap[f'dec.dctx.{i}'] = dctx.clone()  # running d(features) after blocks c_depth-1 .. i
+                base = ns + i * nb
+                grads[base: base + nb] = blk
         if ctx.fold is not None:
             blocks = [params[ns + i * nb: ns + (i + 1) * nb] for i in range(rt.c_depth)]
             dctx, per_block = _context_kv_folded_bwd(rt, dkv_all, ctx.ctxf, ctx.fold[1], ctx.fold[2], blocks)

@@ -321,7 +321,7 @@ def linear_bwd_weight(dy: torch.Tensor, x: torch.Tensor, want_bias: bool = True,
     return dw, db
 
 
-MAX_BATCHED_WEIGHT_GRADS = 8
+MAX_BATCHED_WEIGHT_GRADS = 40
 
 
 def linear_bwd_weight_batched(items, accumulate: bool) -> bool:
