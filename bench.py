@@ -347,10 +347,17 @@ def roofline_of(V, run_once, passes=2, runtime=None, block_flops=None):
             ms = [e0.elapsed_time(e1) for kind, _i, ph, e0, e1 in spans if kind == 'enc' and ph == phase]
             if ms:
                 fb[phase] = statistics.median(ms)
+        # the encoder blocks' weight-gradient launches go out for several blocks at once (after the blocks' own spans): their time,
+        # shared equally by the blocks, belongs to a block's backward
+        dw_ms = sum(e0.elapsed_time(e1) for kind, _i, ph, e0, e1 in spans if kind == 'enc' and ph == 'dw')
+        nblk = len([1 for kind, _i, ph, _e0, _e1 in spans if kind == 'enc' and ph == 'bwd'])
+        if 'bwd' in fb and nblk:
+            fb['bwd'] += dw_ms / nblk
         if 'fwd' in fb:
             tf = block_flops / (fb['fwd'] * 1e-3) / 1e12
             obj = {'what': 'one encoder Block (LayerNorm, qkv, attention, proj + residual, LayerNorm, fc1 + GELU, fc2 + residual) at the bench batch, '
-                           'median over the encoder\'s blocks of the device time between HIP events around the block\'s launches',
+                           'median over the encoder\'s blocks of the device time between HIP events around the block\'s launches (backward: plus the block\'s '
+                           'share of the weight-gradient launches, which go out for several blocks at once)',
                    'flops_fwd': round(block_flops), 'fwd_us': round(1e3 * fb['fwd'], 1), 'fwd_tflops': round(tf, 1),
                    'fwd_frac_of_bf16_peak': round(tf / PEAK_BF16_DENSE_TFLOPS, 4), 'target_frac': 0.40}
             if 'bwd' in fb:

@@ -235,8 +235,8 @@ class _DwBatch:
 
     ROUND = 256
 
-    def __init__(self, rt, blocks=False):
-        self.rt, self.blocks = rt, blocks and rt.group_dw
+    def __init__(self, rt, blocks=False, kind=None):
+        self.rt, self.blocks, self.kind = rt, blocks and rt.group_dw, kind
 
     def __enter__(self):
         self.outer = self.rt.dw_queue
@@ -268,6 +268,11 @@ class _DwBatch:
         if not q:
             return
         self.rt.dw_queue, self.mark = [], 0
+        with _BlockSpan(self.rt, self.kind, len(q), 'dw'):     # (bench.py: these launches belong to the blocks queued since the last flush)
+            self._launch(q)
+
+    @staticmethod
+    def _launch(q):
         for acc in (True, False):
             group = [(dy, x, dw, db) for dy, x, dw, db, a in q if a == acc]
             for i in range(0, len(group), ops.MAX_BATCHED_WEIGHT_GRADS):
@@ -538,7 +543,7 @@ class EncoderFn(torch.autograd.Function):
         dx_lp = _lp(rt, dx)
         grads = [None] * len(params)
         rt.ln_queue = [] if not rt.exact else None
-        with _DwBatch(rt, blocks=True) as dwg:
+        with _DwBatch(rt, blocks=True, kind='enc') as dwg:
             for i in reversed(range(rt.depth)):
                 g1, b1, wqkv, bqkv, wproj, bproj, g2, b2, w1, bb1, w2, bb2 = params[3 + i * nb: 3 + (i + 1) * nb]
                 x, sa, xa, sm = ctx.tape[i]
@@ -881,7 +886,7 @@ class DecoderFn(torch.autograd.Function):
         if ctx.fold is not None:
             dkv_all = torch.empty_like(ctx.fold[0])
             dkv_all3 = dkv_all
-        with _DwBatch(rt, blocks=True) as dwg:
+        with _DwBatch(rt, blocks=True, kind='dec') as dwg:
             for i in reversed(range(rt.c_depth)):
                 P = params[ns + i * nb: ns + (i + 1) * nb]
                 entry = ctx.tape[i]
