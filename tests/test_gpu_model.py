@@ -743,3 +743,36 @@ def test_folded_context_kv_matches_the_per_block_form(vited, gpu):
             assert e_fold < 4e-2 and e_fold <= 1.5 * e_blk + 1e-2, f'{n}: folded {e_fold:.3e} vs per-block {e_blk:.3e} (error against the fp32 kernels)'
             checked += 1
     assert checked == 12
+
+
+@pytest.mark.gpu
+def test_grouped_weight_gradient_launches_match_one_launch_per_block(vited, gpu):
+    """functions._DwBatch(blocks=True) sends the weight gradients of several blocks out in one launch (one row range per product
+    when the tiles fill a round of workgroups) where round 3's first form launched once per block (up to 7 row ranges + a slab
+    sum).  Same products, another fp32 summation order over the rows: every weight / bias gradient agrees to 1e-5 of its norm,
+    everything that does not pass through a weight-gradient launch (logits, LayerNorm gradients) bit for bit."""
+    s = vo.ViTEDShape(depth=3, c_depth=3)
+    torch.manual_seed(5)
+    oracle = vo.OracleViTED(s)
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(72, 2, 3, 64, 64, generator=g).clamp(-1, 1).to(gpu)      # 72 x 64 = 4,608 rows: the products are queued (>= 4,096)
+    y = (torch.rand(72, 4, generator=g) > 0.6).float().to(gpu)
+    runs = {}
+    for grouped in (True, False):
+        model = _hip_model(vited, s, gpu, torch.bfloat16)
+        model.load_state_dict(oracle.state_dict())
+        model.runtime().group_dw = grouped
+        logits = model(x)
+        torch.nn.functional.binary_cross_entropy_with_logits(logits, y).backward()
+        runs[grouped] = (logits.detach(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None})
+    assert torch.equal(runs[True][0], runs[False][0])
+    checked = 0
+    for n, a in runs[True][1].items():
+        b = runs[False][1][n]
+        if 'norm' in n or n in ('cls_token', 'pos_embed'):
+            assert torch.equal(a, b), n
+        else:
+            err = float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+            assert err < 1e-5, f'{n}: {err:.2e}'
+            checked += 1
+    assert checked >= 40
